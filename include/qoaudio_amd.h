@@ -1,0 +1,235 @@
+/*
+ * qoaudio_amd.h -- C ABI of the MI355X-native QOA encode/decode engine.
+ *
+ * This is the drop-in boundary for rafaelcaricio/qoaudio's public API (the crate has no FFI of
+ * its own: its boundary is its Rust API, src/lib.rs).  Every entry point below names the
+ * reference item it replaces (file:line into the reference tree).  Plain pointers and sizes
+ * only -- no torch, no C++ types.  A Rust shim that re-exports the crate's original names over
+ * these symbols is shown in INTEGRATION.md; include/qoaudio.hpp is the C++ mirror used by the
+ * tests.
+ *
+ * All compute (slice search, LMS recurrence, slice decode) runs in hand-written HIP kernels for
+ * gfx950.  There is NO CPU fallback: if no HIP device is usable every compute entry point
+ * returns the IoError code and qoa_last_error_detail() says why.
+ *
+ * Threading: handles are independent and not internally synchronised (the reference's
+ * `&mut self` rule); the library keeps no mutable global state except a thread-local error string.
+ * Device: every call runs on the calling thread's current HIP device (hipSetDevice / torch.cuda.set_device).
+ */
+#ifndef QOAUDIO_AMD_H
+#define QOAUDIO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- format constants: src/lib.rs:12-19 ---- */
+#define QOA_SLICE_LEN 20
+#define QOA_LMS_LEN 4
+#define QOA_HEADER_SIZE 8
+#define QOA_MAGIC 0x716f6166u
+#define QOA_SLICES_PER_FRAME 256
+#define QOA_FRAME_LEN (QOA_SLICES_PER_FRAME * QOA_SLICE_LEN)
+#define QOA_MAX_CHANNELS 8
+
+/* QoaDesc, src/lib.rs:95-102 */
+typedef struct qoa_desc {
+    uint8_t channels;
+    uint32_t sample_rate;
+    uint32_t samples; /* per channel */
+} qoa_desc;
+
+/* EncodeError, src/lib.rs:106-115.  0 = Ok. */
+enum {
+    QOA_OK = 0,
+    QOA_ENCODE_INVALID_CHANNELS = 1,
+    QOA_ENCODE_INVALID_SAMPLE_RATE = 2,
+    QOA_ENCODE_INVALID_SAMPLES = 3,
+    QOA_ENCODE_IO_ERROR = 4 /* also: output buffer too small, HIP failure (see qoa_last_error_detail) */
+};
+
+/* DecodeError, src/lib.rs:866-873.  0 = Ok. */
+enum {
+    QOA_DECODE_NOT_QOA_FILE = 1,
+    QOA_DECODE_NO_SAMPLES = 2,
+    QOA_DECODE_INVALID_FRAME_HEADER = 3,
+    QOA_DECODE_INCOMPATIBLE_FRAME = 4,
+    QOA_DECODE_IO_ERROR = 5 /* also: truncated stream (UnexpectedEof), HIP failure */
+};
+
+/* Display strings of the two error enums, src/lib.rs:877-906 ("IO error: " + detail for IoError). */
+const char *qoa_encode_strerror(int code);
+const char *qoa_decode_strerror(int code);
+/* Detail of the last IoError raised on this thread by this library (HIP error text, "buffer too small"...). */
+const char *qoa_last_error_detail(void);
+/* "qoaudio_amd <version> gfx950" */
+const char *qoa_version(void);
+
+/* Exact encoded size, src/lib.rs:374-378.  channels in 1..=8. */
+size_t qoa_encoded_size(uint32_t channels, uint32_t samples);
+/* qoa_frame_size, src/lib.rs:602-604 (wraps to u16 like the reference). */
+uint16_t qoa_frame_size(uint32_t channels, uint32_t slices);
+
+/* ================================================================== encoder */
+
+typedef struct qoa_encoder qoa_encoder;
+
+/* QoaEncoder::new, src/lib.rs:335-361.  Validation order channels -> sample_rate -> samples. */
+int qoa_encoder_new(const qoa_desc *desc, qoa_encoder **out);
+void qoa_encoder_free(qoa_encoder *enc);
+
+/* QoaEncoder::encode, src/lib.rs:367-398.  n_i16 must equal samples*channels (else InvalidSamples).
+ * pcm/out are HOST pointers; out must hold qoa_encoded_size() bytes. */
+int qoa_encoder_encode(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint8_t *out, size_t cap,
+                       size_t *written);
+
+/* QoaEncoder::write_header, src/lib.rs:404-408. */
+int qoa_encoder_write_header(const qoa_encoder *enc, uint8_t out[8]);
+
+/* QoaEncoder::encode_frame, src/lib.rs:418-439.  Empty / not a multiple of channels / more than
+ * 5120 sample-times -> InvalidSamples.  LMS state (full i32) persists in device memory inside the
+ * handle between calls.  *frame_len receives the sample-times encoded. */
+int qoa_encoder_encode_frame(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint8_t *out, size_t cap,
+                             size_t *written, size_t *frame_len);
+
+/* Test/checkpoint hook ("checkpoint/resume" analogue): read or overwrite the
+ * encoder's carried LMS state, 8 i32 per channel = history[4] then weights[4] (src/lib.rs:70-74, :89). */
+int qoa_encoder_get_lms(qoa_encoder *enc, int32_t *state /* channels*8 */);
+int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state /* channels*8 */);
+
+/* encode_all, src/lib.rs:760-763. */
+int qoa_encode_all(const int16_t *pcm, size_t n_i16, const qoa_desc *desc, uint8_t *out, size_t cap,
+                   size_t *written);
+
+/* ---- batch encode on device-resident buffers (new: semantically encode_all per clip) ---- */
+
+/* One clip of a batch.  pcm_offset counts int16 elements from the pcm base pointer, out_offset
+ * counts bytes from the out base pointer; the clip's output occupies qoa_encoded_size() bytes. */
+typedef struct qoa_clip {
+    uint64_t pcm_offset;
+    uint64_t out_offset;
+    qoa_desc desc;
+} qoa_clip;
+
+typedef struct qoa_encode_plan qoa_encode_plan;
+
+/* flags for qoa_encode_plan_create */
+#define QOA_PLAN_DEFAULT 0u
+#define QOA_PLAN_FORCE_GENERIC_PATH 1u /* debug: run the full-width-multiply/tail path for every slice */
+#define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
+#define QOA_PLAN_CPW_2 (2u << 4)
+#define QOA_PLAN_CPW_4 (4u << 4)
+
+/* Validates every desc like QoaEncoder::new; uploads the chain table to the current device. */
+int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uint32_t flags, qoa_encode_plan **out);
+void qoa_encode_plan_free(qoa_encode_plan *plan);
+/* Bytes the batch reads / writes (algorithmic bytes of one run). */
+int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint64_t *out_bytes,
+                          uint64_t *samples_i16);
+/* Enqueue the encode of the whole batch on `stream` (a hipStream_t, may be NULL).  d_pcm and
+ * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
+int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);
+
+/* ================================================================== decoder */
+
+/* FrameHeader, src/lib.rs:774-781 */
+typedef struct qoa_frame_header {
+    uint8_t num_channels;
+    uint32_t sample_rate;
+    uint16_t num_samples_per_channel;
+} qoa_frame_header;
+
+/* ProcessingMode, src/lib.rs:31-45 */
+enum { QOA_MODE_FIXED_SAMPLES = 0, QOA_MODE_STREAMING = 1 };
+typedef struct qoa_mode {
+    int kind;
+    uint8_t channels;
+    uint32_t sample_rate;
+    uint32_t samples;
+} qoa_mode;
+
+/* QoaItem (src/lib.rs:656-659) plus the iterator's None / Some(Err) outcomes */
+enum { QOA_ITEM_SAMPLE = 0, QOA_ITEM_FRAME_HEADER = 1, QOA_ITEM_END = 2, QOA_ITEM_ERROR = 3 };
+typedef struct qoa_item {
+    int kind;
+    int16_t sample;
+    qoa_frame_header header;
+    int error; /* QOA_DECODE_* when kind == QOA_ITEM_ERROR */
+} qoa_item;
+
+typedef struct qoa_decoder qoa_decoder;
+
+/* QoaDecoder::new over an in-memory reader, src/lib.rs:127-169 (bytes are copied).  A generic
+ * io::Read cannot cross a C ABI: the host shim reads the bytes, the GPU decodes whole frames and
+ * the iterator drains the decoded PCM in the reference's exact item order. */
+int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **out);
+/* QoaDecoder::new_streaming, src/lib.rs:632-638 */
+int qoa_decoder_new_streaming(qoa_decoder **out);
+void qoa_decoder_free(qoa_decoder *dec);
+/* QoaDecoder::mode, src/lib.rs:180-182 */
+int qoa_decoder_mode(const qoa_decoder *dec, qoa_mode *mode);
+/* QoaDecoder::current_frame_header, src/lib.rs:186-188 */
+int qoa_decoder_current_frame_header(const qoa_decoder *dec, qoa_frame_header *h);
+/* QoaDecoder::total_duration, src/lib.rs:190-201: seconds, or a negative value for None (streaming). */
+double qoa_decoder_total_duration(const qoa_decoder *dec);
+/* Iterator::next, src/lib.rs:668-692.  After QOA_ITEM_ERROR the iterator is finished. */
+int qoa_decoder_next(qoa_decoder *dec, qoa_item *item);
+/* Bulk form of next(): copies up to cap consecutive Sample items, stops early at the next
+ * FrameHeader / END / ERROR (which the following qoa_decoder_next call returns).  Returns the count. */
+size_t qoa_decoder_read_samples(qoa_decoder *dec, int16_t *out, size_t cap);
+/* QoaDecoder::decode_frame, src/lib.rs:641-651: append bytes, drain.  *n_out = samples produced;
+ * if out is NULL or cap too small the samples stay buffered for a second call with len == 0. */
+int qoa_decoder_decode_frame(qoa_decoder *dec, const uint8_t *frame, size_t len, int16_t *out, size_t cap,
+                             size_t *n_out);
+
+/* decode_all, src/lib.rs:713-747.  Call with out == NULL to obtain *n_out / channels / rate first. */
+int qoa_decode_all(const uint8_t *bytes, size_t len, uint8_t *channels, uint32_t *sample_rate, int16_t *out,
+                   size_t cap, size_t *n_out);
+
+/* Host-only scan of a stream (no GPU work): walks it exactly as the reference decoder's reader would
+ * (src/lib.rs:127-169, :205-289, :320-328) and reports how the iteration over it ends.
+ *   *terminal  0 = clean end, else the QOA_DECODE_* error that QoaDecoder::new or the iterator raises;
+ *   *in_new    1 if that error is raised by QoaDecoder::new itself (before any item);
+ *   *n_frames  FrameHeader items the iterator yields (the streaming mode's leading default header excluded);
+ *   *n_samples Sample items it yields. */
+typedef struct qoa_stream_info {
+    qoa_mode mode;
+    int terminal;
+    int in_new;
+    uint64_t n_frames;
+    uint64_t n_samples;
+} qoa_stream_info;
+int qoa_stream_scan(const uint8_t *bytes, size_t len, qoa_stream_info *info);
+
+/* ---- batch decode on device-resident buffers ---- */
+
+typedef struct qoa_decode_plan qoa_decode_plan;
+
+/* Build the frame table by parsing host copies of the streams exactly like the reference decoder
+ * walks them (src/lib.rs:205-289, :320-328).  streams[i] points at len[i] bytes; the device copy of
+ * stream i must start at byte in_offset[i] of d_in, and its PCM lands at int16 index out_offset[i]
+ * of d_out.  status[i] (optional) receives 0 or the QOA_DECODE_* error that ends stream i;
+ * samples_out[i] (optional) the int16 count it yields before that. */
+int qoa_decode_plan_from_streams(const uint8_t *const *streams, const size_t *len, const uint64_t *in_offset,
+                                 const uint64_t *out_offset, size_t n_streams, int *status, uint64_t *samples_out,
+                                 qoa_decode_plan **out);
+/* Frame table for streams produced by qoa_encode_plan_run over the same clips (layout is a pure
+ * function of the desc, src/lib.rs:374-378); here clip.pcm_offset is the PCM destination and
+ * clip.out_offset the encoded source.  The kernel verifies every frame header against the plan. */
+int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips, qoa_decode_plan **out);
+void qoa_decode_plan_free(qoa_decode_plan *plan);
+int qoa_decode_plan_bytes(const qoa_decode_plan *plan, uint64_t *in_bytes, uint64_t *pcm_bytes,
+                          uint64_t *samples_i16);
+/* Enqueue the decode on `stream`.  d_in / d_out are DEVICE pointers.  Asynchronous. */
+int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream);
+/* After synchronising: number of frames whose header on the device disagreed with the plan
+ * (from_clips plans only; 0 for a well-formed batch). */
+int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QOAUDIO_AMD_H */

@@ -1,0 +1,123 @@
+"""ctypes loader for libqoaudio_amd.so (the C ABI of include/qoaudio_amd.h).
+
+The library is the product: if it is missing this module raises -- there is no Python or CPU
+fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqoaudio_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/qoaudio_amd.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = [
+    "qoa_encode_strerror", "qoa_decode_strerror", "qoa_last_error_detail", "qoa_version",
+    "qoa_encoded_size", "qoa_frame_size",
+    "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
+    "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_encode_all",
+    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run",
+    "qoa_decoder_new", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
+    "qoa_decoder_current_frame_header", "qoa_decoder_total_duration", "qoa_decoder_next",
+    "qoa_decoder_read_samples", "qoa_decoder_decode_frame", "qoa_decode_all",
+    "qoa_stream_scan", "qoa_decode_plan_from_streams", "qoa_decode_plan_from_clips", "qoa_decode_plan_free",
+    "qoa_decode_plan_bytes", "qoa_decode_plan_run", "qoa_decode_plan_mismatches",
+]
+
+
+class Desc(C.Structure):
+    _fields_ = [("channels", C.c_uint8), ("sample_rate", C.c_uint32), ("samples", C.c_uint32)]
+
+
+class Clip(C.Structure):
+    _fields_ = [("pcm_offset", C.c_uint64), ("out_offset", C.c_uint64), ("desc", Desc)]
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("num_channels", C.c_uint8), ("sample_rate", C.c_uint32), ("num_samples_per_channel", C.c_uint16)]
+
+
+class Mode(C.Structure):
+    _fields_ = [("kind", C.c_int), ("channels", C.c_uint8), ("sample_rate", C.c_uint32), ("samples", C.c_uint32)]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("mode", Mode), ("terminal", C.c_int), ("in_new", C.c_int), ("n_frames", C.c_uint64),
+                ("n_samples", C.c_uint64)]
+
+
+class Item(C.Structure):
+    _fields_ = [("kind", C.c_int), ("sample", C.c_int16), ("header", FrameHeader), ("error", C.c_int)]
+
+
+def build(force=False):
+    """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(qoaudio_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
+    szp = C.POINTER(C.c_size_t)
+    L.qoa_encode_strerror.restype = C.c_char_p
+    L.qoa_encode_strerror.argtypes = [C.c_int]
+    L.qoa_decode_strerror.restype = C.c_char_p
+    L.qoa_decode_strerror.argtypes = [C.c_int]
+    L.qoa_last_error_detail.restype = C.c_char_p
+    L.qoa_version.restype = C.c_char_p
+    L.qoa_encoded_size.restype = sz
+    L.qoa_encoded_size.argtypes = [C.c_uint32, C.c_uint32]
+    L.qoa_frame_size.restype = C.c_uint16
+    L.qoa_frame_size.argtypes = [C.c_uint32, C.c_uint32]
+    L.qoa_encoder_new.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
+    L.qoa_encoder_free.argtypes = [vp]
+    L.qoa_encoder_free.restype = None
+    L.qoa_encoder_encode.argtypes = [vp, vp, sz, vp, sz, szp]
+    L.qoa_encoder_write_header.argtypes = [vp, vp]
+    L.qoa_encoder_encode_frame.argtypes = [vp, vp, sz, vp, sz, szp, szp]
+    L.qoa_encoder_get_lms.argtypes = [vp, vp]
+    L.qoa_encoder_set_lms.argtypes = [vp, vp]
+    L.qoa_encode_all.argtypes = [vp, sz, C.POINTER(Desc), vp, sz, szp]
+    L.qoa_encode_plan_create.argtypes = [C.POINTER(Clip), sz, C.c_uint32, C.POINTER(vp)]
+    L.qoa_encode_plan_free.argtypes = [vp]
+    L.qoa_encode_plan_free.restype = None
+    L.qoa_encode_plan_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.qoa_encode_plan_run.argtypes = [vp, vp, vp, vp]
+    L.qoa_decoder_new.argtypes = [vp, sz, C.POINTER(vp)]
+    L.qoa_decoder_new_streaming.argtypes = [C.POINTER(vp)]
+    L.qoa_decoder_free.argtypes = [vp]
+    L.qoa_decoder_free.restype = None
+    L.qoa_decoder_mode.argtypes = [vp, C.POINTER(Mode)]
+    L.qoa_decoder_current_frame_header.argtypes = [vp, C.POINTER(FrameHeader)]
+    L.qoa_decoder_total_duration.argtypes = [vp]
+    L.qoa_decoder_total_duration.restype = C.c_double
+    L.qoa_decoder_next.argtypes = [vp, C.POINTER(Item)]
+    L.qoa_decoder_read_samples.argtypes = [vp, vp, sz]
+    L.qoa_decoder_read_samples.restype = sz
+    L.qoa_decoder_decode_frame.argtypes = [vp, vp, sz, vp, sz, szp]
+    L.qoa_decode_all.argtypes = [vp, sz, u8p, C.POINTER(C.c_uint32), vp, sz, szp]
+    L.qoa_stream_scan.argtypes = [vp, sz, C.POINTER(StreamInfo)]
+    L.qoa_decode_plan_from_streams.argtypes = [C.POINTER(vp), szp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), sz,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(vp)]
+    L.qoa_decode_plan_from_clips.argtypes = [C.POINTER(Clip), sz, C.POINTER(vp)]
+    L.qoa_decode_plan_free.argtypes = [vp]
+    L.qoa_decode_plan_free.restype = None
+    L.qoa_decode_plan_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.qoa_decode_plan_run.argtypes = [vp, vp, vp, vp]
+    L.qoa_decode_plan_mismatches.argtypes = [vp, C.POINTER(C.c_uint32)]
+    _lib = L
+    return L

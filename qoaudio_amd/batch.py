@@ -1,0 +1,172 @@
+"""Batch encode/decode on device-resident buffers: the data-parallel hot path.
+
+torch is plumbing here (device memory, streams); the work is qoa_encode_plan_run /
+qoa_decode_plan_run in libqoaudio_amd.so.  A batch is semantically `encode_all` per clip
+(src/lib.rs:760-763): clips are independent, every (clip, channel) is one serial chain.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .api import DecodeError, EncodeError, QoaDesc, encoded_size
+
+PLAN_DEFAULT = 0
+PLAN_FORCE_GENERIC_PATH = 1
+PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
+
+
+def _clips_array(clips: Sequence[Tuple[int, int, QoaDesc]]):
+    arr = (_lib.Clip * len(clips))()
+    for i, (pcm_off, out_off, d) in enumerate(clips):
+        arr[i].pcm_offset = pcm_off
+        arr[i].out_offset = out_off
+        arr[i].desc = d._c()
+    return arr
+
+
+def _stream_ptr(stream: Optional[torch.cuda.Stream]):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor (qoaudio_amd has no CPU path)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous {dtype}")
+
+
+class EncodePlan:
+    """Chain table for a batch of clips, resident on the current device."""
+
+    def __init__(self, clips: Sequence[Tuple[int, int, QoaDesc]], flags: int = PLAN_DEFAULT):
+        self._h = C.c_void_p(None)
+        arr = _clips_array(clips)
+        rc = _lib.lib().qoa_encode_plan_create(arr, len(clips), flags, C.byref(self._h))
+        if rc:
+            self._h = None
+            raise EncodeError(rc)
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.lib().qoa_encode_plan_bytes(self._h, C.byref(a), C.byref(b), C.byref(c))
+        self.pcm_bytes, self.out_bytes, self.samples = a.value, b.value, c.value
+
+    def __del__(self):
+        try:  # module globals may already be torn down at interpreter exit
+            if getattr(self, "_h", None):
+                _lib.lib().qoa_encode_plan_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def run(self, pcm: torch.Tensor, out: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Enqueue the batch encode (asynchronous).  pcm: int16 device tensor, out: uint8 device tensor."""
+        _require_cuda(pcm, torch.int16, "pcm")
+        _require_cuda(out, torch.uint8, "out")
+        rc = _lib.lib().qoa_encode_plan_run(self._h, C.c_void_p(pcm.data_ptr()), C.c_void_p(out.data_ptr()),
+                                            _stream_ptr(stream))
+        if rc:
+            raise EncodeError(rc)
+
+
+class DecodePlan:
+    """Frame table for a batch of encoded streams, resident on the current device."""
+
+    def __init__(self):
+        self._h = C.c_void_p(None)
+        self.status: List[int] = []
+        self.samples_out: List[int] = []
+
+    @classmethod
+    def from_clips(cls, clips: Sequence[Tuple[int, int, QoaDesc]]):
+        """Streams laid out as EncodePlan wrote them: (pcm_offset = PCM destination, out_offset = encoded source)."""
+        self = cls()
+        arr = _clips_array(clips)
+        rc = _lib.lib().qoa_decode_plan_from_clips(arr, len(clips), C.byref(self._h))
+        if rc:
+            self._h = None
+            raise DecodeError(rc)
+        self._fill_bytes()
+        return self
+
+    @classmethod
+    def from_streams(cls, streams: Sequence[bytes], in_offsets: Sequence[int], out_offsets: Sequence[int]):
+        """Parse host copies of arbitrary QOA streams the way the reference decoder walks them."""
+        self = cls()
+        n = len(streams)
+        bufs = [np.frombuffer(bytes(s), dtype=np.uint8) for s in streams]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data_as(C.c_void_p).value or 0 for b in bufs])
+        lens = (C.c_size_t * n)(*[b.size for b in bufs])
+        ino = (C.c_uint64 * n)(*in_offsets)
+        outo = (C.c_uint64 * n)(*out_offsets)
+        status = (C.c_int * n)()
+        nout = (C.c_uint64 * n)()
+        rc = _lib.lib().qoa_decode_plan_from_streams(ptrs, lens, ino, outo, n, status, nout, C.byref(self._h))
+        if rc:
+            self._h = None
+            raise DecodeError(rc)
+        self.status = list(status)
+        self.samples_out = list(nout)
+        self._fill_bytes()
+        return self
+
+    def _fill_bytes(self):
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.lib().qoa_decode_plan_bytes(self._h, C.byref(a), C.byref(b), C.byref(c))
+        self.in_bytes, self.pcm_bytes, self.samples = a.value, b.value, c.value
+
+    def __del__(self):
+        try:  # module globals may already be torn down at interpreter exit
+            if getattr(self, "_h", None):
+                _lib.lib().qoa_decode_plan_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def run(self, enc: torch.Tensor, pcm: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        _require_cuda(enc, torch.uint8, "enc")
+        _require_cuda(pcm, torch.int16, "pcm")
+        rc = _lib.lib().qoa_decode_plan_run(self._h, C.c_void_p(enc.data_ptr()), C.c_void_p(pcm.data_ptr()),
+                                            _stream_ptr(stream))
+        if rc:
+            raise DecodeError(rc)
+
+    def mismatches(self) -> int:
+        n = C.c_uint32(0)
+        rc = _lib.lib().qoa_decode_plan_mismatches(self._h, C.byref(n))
+        if rc:
+            raise DecodeError(rc)
+        return n.value
+
+
+def uniform_clips(n_clips: int, desc: QoaDesc):
+    """Contiguous layout of n identical-shape clips: PCM [n, samples, channels], encoded [n, encoded_size]."""
+    per_pcm = desc.samples * desc.channels
+    per_enc = encoded_size(desc.channels, desc.samples)
+    return [(i * per_pcm, i * per_enc, desc) for i in range(n_clips)], per_pcm, per_enc
+
+
+def encode_batch(pcm: torch.Tensor, sample_rate: int, flags: int = PLAN_DEFAULT) -> torch.Tensor:
+    """pcm: int16 device tensor [n_clips, samples, channels] -> uint8 device tensor [n_clips, encoded_size]."""
+    n, samples, channels = pcm.shape
+    desc = QoaDesc(channels, sample_rate, samples)
+    clips, _, per_enc = uniform_clips(n, desc)
+    plan = EncodePlan(clips, flags)
+    out = torch.empty((n, per_enc), dtype=torch.uint8, device=pcm.device)
+    plan.run(pcm, out)
+    return out
+
+
+def decode_batch(enc: torch.Tensor, desc: QoaDesc) -> torch.Tensor:
+    """enc: uint8 device tensor [n_clips, encoded_size] as encode_batch wrote it -> int16 [n, samples, channels]."""
+    n = enc.shape[0]
+    clips, _, _ = uniform_clips(n, desc)
+    plan = DecodePlan.from_clips(clips)
+    pcm = torch.empty((n, desc.samples, desc.channels), dtype=torch.int16, device=enc.device)
+    plan.run(enc, pcm)
+    bad = plan.mismatches()  # synchronises
+    if bad:
+        raise DecodeError(3)
+    return pcm

@@ -1,0 +1,847 @@
+// qoa_capi.cpp -- the C ABI of include/qoaudio_amd.h: host logic around the gfx950 kernels.
+//
+// Host responsibilities: validation in the reference's order, the exact output-size formula,
+// chain/frame tables, staging between host pointers and HBM, walking decoder streams, and the
+// pull-iterator's item order.  All sample arithmetic is in qoa_kernels.hip.  There is no CPU
+// compute path: when HIP is unusable every compute entry point returns the IoError code.
+#include "../../include/qoaudio_amd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "qoa_format.h"
+#include "qoa_host.h"
+#include "qoa_kernels.h"
+
+using namespace qoa;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_detail;
+
+static int fail_hip(hipError_t e, const char *what, int code) {
+    g_detail = std::string(what) + ": " + hipGetErrorString(e);
+    return code;
+}
+static int fail_msg(const char *msg, int code) {
+    g_detail = msg;
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                          \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) return fail_hip(_e, #expr, (code));    \
+    } while (0)
+
+extern "C" const char *qoa_last_error_detail(void) { return g_detail.c_str(); }
+extern "C" const char *qoa_version(void) { return "qoaudio_amd 0.1.0 gfx950"; }
+
+// Display strings, src/lib.rs:877-906
+extern "C" const char *qoa_encode_strerror(int code) {
+    switch (code) {
+    case QOA_OK: return "Ok";
+    case QOA_ENCODE_INVALID_CHANNELS: return "Invalid number of channels (must be 1-8)";
+    case QOA_ENCODE_INVALID_SAMPLE_RATE: return "Invalid sample rate (must be > 0)";
+    case QOA_ENCODE_INVALID_SAMPLES: return "Invalid number of samples (must be > 0)";
+    case QOA_ENCODE_IO_ERROR: return "IO error: ";
+    default: return "unknown encode error";
+    }
+}
+extern "C" const char *qoa_decode_strerror(int code) {
+    switch (code) {
+    case QOA_OK: return "Ok";
+    case QOA_DECODE_NOT_QOA_FILE: return "File is not a qoa file";
+    case QOA_DECODE_NO_SAMPLES: return "File has no samples";
+    case QOA_DECODE_INVALID_FRAME_HEADER: return "File has invalid frame header";
+    case QOA_DECODE_INCOMPATIBLE_FRAME: return "Incompatible frame header";
+    case QOA_DECODE_IO_ERROR: return "IO error: ";
+    default: return "unknown decode error";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pure format helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t qoa_encoded_size(uint32_t channels, uint32_t samples) { // src/lib.rs:374-378
+    size_t total = samples;
+    size_t num_slices = (total + kSliceLen - 1) / kSliceLen;
+    size_t num_frames = (total + kFrameLen - 1) / kFrameLen;
+    return kHeaderSize + num_frames * (8 + kLmsLen * 4 * (size_t)channels) + num_slices * 8 * (size_t)channels;
+}
+extern "C" uint16_t qoa_frame_size(uint32_t channels, uint32_t slices) { // src/lib.rs:602-604
+    return (uint16_t)(8 + kLmsLen * 4 * channels + 8 * slices * channels);
+}
+
+static int validate_desc(const qoa_desc *d) { // src/lib.rs:336-344, in this order
+    if (d->channels == 0 || d->channels > kMaxChannels) return QOA_ENCODE_INVALID_CHANNELS;
+    if (d->sample_rate == 0) return QOA_ENCODE_INVALID_SAMPLE_RATE;
+    if (d->samples == 0) return QOA_ENCODE_INVALID_SAMPLES;
+    return QOA_OK;
+}
+
+static inline uint32_t be32(const uint8_t *p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+static inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+
+// Chains-per-wavefront heuristic.  Measured on MI355X (profiles/r01_first_contact.txt): the kernel is
+// integer-VALU-issue bound and a gfx950 SIMD issues these integer ops at one wave-instruction per
+// ~4 cycles whether one or two wavefronts are resident, so throughput = 1 / (wave-instructions per
+// SIMD).  Packing 4 chains into each wavefront (all 64 lanes busy) is therefore never slower than
+// spreading them out, and is 1.8x faster once there are more wavefronts than SIMDs (1024).  Small
+// batches use fewer chains per wavefront only to keep ragged clips from idling their wave-mates.
+static int pick_cpw(size_t n_chains, uint32_t flags) {
+    int forced = (int)((flags >> 4) & 7u);
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    if (n_chains >= 2048) return 4;
+    if (n_chains >= 1024) return 2;
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device buffer helper
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(n, 256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// batch encode plan
+// ------------------------------------------------------------------------------------------------
+struct EncGroup {
+    int nch = 0;
+    int cpw = 1;
+    unsigned n = 0;
+    unsigned lds = 0;
+    DevBuf chains;
+    DevBuf lms;
+};
+
+struct qoa_encode_plan {
+    std::vector<EncGroup *> groups;
+    uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;
+    uint32_t flags = 0;
+    ~qoa_encode_plan() { for (auto *g : groups) delete g; }
+};
+
+static void make_chains(const qoa_clip &c, bool file_header, uint32_t samples_now, std::vector<EncChain> &v) {
+    for (unsigned ch = 0; ch < c.desc.channels; ch++) {
+        EncChain e;
+        e.pcm_off = c.pcm_offset + ch;
+        e.out_off = c.out_offset;
+        e.samples = samples_now;
+        e.hdr_hi = ((uint32_t)c.desc.channels << 24) | c.desc.sample_rate; // (ch<<56)|(rate<<32), src/lib.rs:448-449
+        e.total_samples = c.desc.samples;
+        e.channel = (uint16_t)ch;
+        e.flags = file_header ? 1 : 0;
+        e.pad = 0;
+        v.push_back(e);
+    }
+}
+
+extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uint32_t flags, qoa_encode_plan **out) {
+    if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
+    *out = nullptr;
+    std::vector<EncChain> per_nch[kMaxChannels + 1];
+    uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;
+    for (size_t i = 0; i < n_clips; i++) {
+        int rc = validate_desc(&clips[i].desc);
+        if (rc) return rc;
+        if (clips[i].out_offset % 8 != 0) return fail_msg("qoa_clip.out_offset must be 8-byte aligned", QOA_ENCODE_IO_ERROR);
+        make_chains(clips[i], true, clips[i].desc.samples, per_nch[clips[i].desc.channels]);
+        uint64_t n = (uint64_t)clips[i].desc.samples * clips[i].desc.channels;
+        samples += n;
+        pcm_bytes += n * 2;
+        out_bytes += qoa_encoded_size(clips[i].desc.channels, clips[i].desc.samples);
+    }
+    auto *plan = new (std::nothrow) qoa_encode_plan();
+    if (!plan) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
+    plan->pcm_bytes = pcm_bytes;
+    plan->out_bytes = out_bytes;
+    plan->samples = samples;
+    plan->flags = flags;
+    for (int nch = 1; nch <= kMaxChannels; nch++) {
+        auto &v = per_nch[nch];
+        if (v.empty()) continue;
+        auto *g = new EncGroup();
+        plan->groups.push_back(g);
+        g->nch = nch;
+        g->n = (unsigned)v.size();
+        g->cpw = pick_cpw(v.size(), flags);
+        hipError_t e = g->chains.reserve(v.size() * sizeof(EncChain));
+        if (e == hipSuccess) e = g->lms.reserve(v.size() * 8 * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpy(g->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete plan;
+            return fail_hip(e, "encode plan upload", QOA_ENCODE_IO_ERROR);
+        }
+    }
+    *out = plan;
+    return QOA_OK;
+}
+
+extern "C" void qoa_encode_plan_free(qoa_encode_plan *plan) { delete plan; }
+
+extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint64_t *out_bytes,
+                                     uint64_t *samples_i16) {
+    if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
+    if (pcm_bytes) *pcm_bytes = plan->pcm_bytes;
+    if (out_bytes) *out_bytes = plan->out_bytes;
+    if (samples_i16) *samples_i16 = plan->samples;
+    return QOA_OK;
+}
+
+// kernel flags: bit0 force generic path, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352)
+extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
+    if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
+    unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u);
+    for (auto *g : plan->groups) {
+        HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
+                              kflags, g->lds, (hipStream_t)stream),
+                QOA_ENCODE_IO_ERROR);
+    }
+    return QOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QoaEncoder handle
+// ------------------------------------------------------------------------------------------------
+struct qoa_encoder {
+    qoa_desc desc{};
+    hipStream_t stream = nullptr;
+    DevBuf lms, chains, pcm, out;
+    ~qoa_encoder() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+extern "C" int qoa_encoder_new(const qoa_desc *desc, qoa_encoder **out) {
+    if (!out || !desc) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    auto *e = new (std::nothrow) qoa_encoder();
+    if (!e) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
+    e->desc = *desc;
+    // initial LMS state: history 0, weights [0, 0, -(1<<13), 1<<14]  (src/lib.rs:346-352)
+    int32_t init[kMaxChannels * 8];
+    for (int c = 0; c < kMaxChannels; c++) {
+        int32_t *s = init + c * 8;
+        s[0] = s[1] = s[2] = s[3] = 0;
+        s[4] = 0; s[5] = 0; s[6] = -(1 << 13); s[7] = 1 << 14;
+    }
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = e->lms.reserve(sizeof init);
+    if (err == hipSuccess) err = e->chains.reserve(kMaxChannels * sizeof(EncChain));
+    if (err == hipSuccess) err = hipMemcpy(e->lms.p, init, sizeof init, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        delete e;
+        return fail_hip(err, "qoa_encoder_new", QOA_ENCODE_IO_ERROR);
+    }
+    *out = e;
+    return QOA_OK;
+}
+
+extern "C" void qoa_encoder_free(qoa_encoder *enc) { delete enc; }
+
+extern "C" int qoa_encoder_write_header(const qoa_encoder *enc, uint8_t out[8]) { // src/lib.rs:404-408
+    if (!enc || !out) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
+    out[0] = 'q'; out[1] = 'o'; out[2] = 'a'; out[3] = 'f';
+    uint32_t s = enc->desc.samples;
+    out[4] = (uint8_t)(s >> 24); out[5] = (uint8_t)(s >> 16); out[6] = (uint8_t)(s >> 8); out[7] = (uint8_t)s;
+    return QOA_OK;
+}
+
+// Shared by encode() and encode_frame(): encode `frame_len_total` sample-times of the handle's stream
+// starting from the carried LMS state, with or without the 8-byte file header.
+static int encoder_run(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint32_t sample_times, bool file_header,
+                       uint8_t *out, size_t out_bytes) {
+    qoa_clip clip;
+    clip.pcm_offset = 0;
+    clip.out_offset = 0;
+    clip.desc = enc->desc;
+    std::vector<EncChain> v;
+    make_chains(clip, file_header, sample_times, v);
+    HIP_TRY(enc->pcm.reserve(n_i16 * 2), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(enc->out.reserve(out_bytes), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpyAsync(enc->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice, enc->stream),
+            QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpyAsync(enc->pcm.p, pcm, n_i16 * 2, hipMemcpyHostToDevice, enc->stream), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(launch_encode(1, enc->desc.channels, (const int16_t *)enc->pcm.p, (uint8_t *)enc->out.p,
+                          (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u, 0u,
+                          enc->stream),
+            QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpyAsync(out, enc->out.p, out_bytes, hipMemcpyDeviceToHost, enc->stream), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipStreamSynchronize(enc->stream), QOA_ENCODE_IO_ERROR);
+    return QOA_OK;
+}
+
+extern "C" int qoa_encoder_encode(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint8_t *out, size_t cap,
+                                  size_t *written) { // src/lib.rs:367-398
+    if (!enc) return fail_msg("null encoder", QOA_ENCODE_IO_ERROR);
+    size_t channels = enc->desc.channels, total = enc->desc.samples;
+    if (n_i16 != total * channels) return QOA_ENCODE_INVALID_SAMPLES; // :368-370
+    size_t need = qoa_encoded_size((uint32_t)channels, (uint32_t)total);
+    if (!out || cap < need) return fail_msg("output buffer smaller than qoa_encoded_size()", QOA_ENCODE_IO_ERROR);
+    if (!pcm) return fail_msg("null pcm", QOA_ENCODE_IO_ERROR);
+    int rc = encoder_run(enc, pcm, n_i16, (uint32_t)total, true, out, need);
+    if (rc) return rc;
+    if (written) *written = need;
+    return QOA_OK;
+}
+
+extern "C" int qoa_encoder_encode_frame(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint8_t *out, size_t cap,
+                                        size_t *written, size_t *frame_len_out) { // src/lib.rs:418-439
+    if (!enc) return fail_msg("null encoder", QOA_ENCODE_IO_ERROR);
+    size_t channels = enc->desc.channels;
+    if (n_i16 == 0 || n_i16 % channels != 0) return QOA_ENCODE_INVALID_SAMPLES; // :424-426
+    size_t frame_len = n_i16 / channels;
+    if (frame_len > (size_t)kFrameLen) return QOA_ENCODE_INVALID_SAMPLES; // :428-430
+    size_t slices = (frame_len + kSliceLen - 1) / kSliceLen;
+    size_t frame_size = qoa_frame_size((uint32_t)channels, (uint32_t)slices);
+    if (!out || cap < frame_size) return fail_msg("output buffer smaller than the frame", QOA_ENCODE_IO_ERROR);
+    if (!pcm) return fail_msg("null pcm", QOA_ENCODE_IO_ERROR);
+    int rc = encoder_run(enc, pcm, n_i16, (uint32_t)frame_len, false, out, frame_size);
+    if (rc) return rc;
+    if (written) *written = frame_size;
+    if (frame_len_out) *frame_len_out = frame_len;
+    return QOA_OK;
+}
+
+extern "C" int qoa_encoder_get_lms(qoa_encoder *enc, int32_t *state) {
+    if (!enc || !state) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(state, enc->lms.p, enc->desc.channels * 8 * sizeof(int32_t), hipMemcpyDeviceToHost),
+            QOA_ENCODE_IO_ERROR);
+    return QOA_OK;
+}
+extern "C" int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state) {
+    if (!enc || !state) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(enc->lms.p, state, enc->desc.channels * 8 * sizeof(int32_t), hipMemcpyHostToDevice),
+            QOA_ENCODE_IO_ERROR);
+    return QOA_OK;
+}
+
+extern "C" int qoa_encode_all(const int16_t *pcm, size_t n_i16, const qoa_desc *desc, uint8_t *out, size_t cap,
+                              size_t *written) { // src/lib.rs:760-763
+    qoa_encoder *e = nullptr;
+    int rc = qoa_encoder_new(desc, &e);
+    if (rc) return rc;
+    rc = qoa_encoder_encode(e, pcm, n_i16, out, cap, written);
+    qoa_encoder_free(e);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream walking (host bytes only)
+// ------------------------------------------------------------------------------------------------
+int Walker::walk(const uint8_t *data, size_t len, size_t *pos_io, std::vector<FrameRec> &frames) {
+    size_t pos = *pos_io;
+    for (;;) {
+        // read_u64_be of the frame header: UnexpectedEof -- even on a partial header -- is the clean end
+        // (src/lib.rs:206-216); Cursor::read_exact leaves the cursor at EOF.
+        if (len - pos < 8) { pos = len; *pos_io = pos; return kTermEnd; }
+        uint64_t fh = be64(data + pos);
+        size_t hpos = pos;
+        pos += 8;
+        uint8_t nch = (uint8_t)(fh >> 56);
+        uint32_t rate = (uint32_t)((fh >> 32) & 0xffffff);
+        uint16_t nspc = (uint16_t)((fh >> 16) & 0xffff);
+        uint16_t fsize = (uint16_t)(fh & 0xffff);
+        *pos_io = pos;
+        if (nch == 0 || rate == 0) return QOA_DECODE_INVALID_FRAME_HEADER;          // :227-229
+        size_t non_sample = kHeaderSize + kLmsLen * 4 * (size_t)nch;                // :231-235
+        if ((size_t)fsize <= non_sample) return QOA_DECODE_INVALID_FRAME_HEADER;
+        size_t num_slices = ((size_t)fsize - non_sample) / 8;
+        if (num_slices % nch != 0) return QOA_DECODE_INVALID_FRAME_HEADER;          // :239-241
+        if (num_slices / nch > (size_t)kSlicesPerFrame) return QOA_DECODE_INVALID_FRAME_HEADER; // :242-244
+        if (mode == kFixed) {                                                       // :246-259
+            if (first) { fixed_channels = nch; fixed_rate = rate; }
+            else if (nch != fixed_channels || rate != fixed_rate) return QOA_DECODE_INCOMPATIBLE_FRAME;
+        }
+        first = false;
+        // LMS block: 16 bytes per channel, read as two u64 each (src/lib.rs:271-281)
+        size_t lms_bytes = 16 * (size_t)nch;
+        if (len - pos < lms_bytes) { pos = len; *pos_io = pos; return QOA_DECODE_IO_ERROR; }
+        pos += lms_bytes;
+        // slice rows are consumed while num_samples_per_channel_remaining > 0 (src/lib.rs:679-682, :320-328):
+        // the header's frame_size is validated above but does NOT drive the reader.
+        size_t rows_needed = ((size_t)nspc + kSliceLen - 1) / kSliceLen;
+        size_t row_bytes = 8 * (size_t)nch;
+        size_t rows_avail = std::min(rows_needed, (len - pos) / row_bytes);
+        FrameRec f;
+        f.pos = hpos;
+        f.channels = nch;
+        f.rate = rate;
+        f.nspc = nspc;
+        f.rows = (uint32_t)rows_avail;
+        f.n_out = rows_avail == rows_needed ? nspc : (uint32_t)(rows_avail * kSliceLen);
+        frames.push_back(f);
+        if (rows_avail < rows_needed) { pos = len; *pos_io = pos; return QOA_DECODE_IO_ERROR; }
+        pos += rows_needed * row_bytes;
+        *pos_io = pos;
+    }
+}
+
+static void frames_to_chains(const std::vector<FrameRec> &frames, size_t first_frame, uint64_t in_base, uint64_t out_base,
+                             bool verify, std::vector<DecChain> &chains, uint64_t *samples_total) {
+    uint64_t out = out_base;
+    for (size_t i = first_frame; i < frames.size(); i++) {
+        const FrameRec &f = frames[i];
+        if (f.rows > 0 && f.n_out > 0) {
+            for (unsigned c = 0; c < f.channels; c++) {
+                DecChain d;
+                d.frame_off = in_base + f.pos;
+                d.out_off = out + c;
+                d.n_out = f.n_out;
+                d.rows = (uint16_t)std::min<uint32_t>(f.rows, (f.n_out + kSliceLen - 1) / kSliceLen);
+                d.channels = f.channels;
+                d.channel = (uint8_t)c;
+                d.expect_hi = d.expect_lo = 0;
+                (void)verify;
+                chains.push_back(d);
+            }
+        }
+        out += (uint64_t)f.n_out * f.channels;
+    }
+    if (samples_total) *samples_total = out - out_base;
+}
+
+extern "C" int qoa_stream_scan(const uint8_t *bytes, size_t len, qoa_stream_info *info) {
+    if (!info) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    memset(info, 0, sizeof *info);
+    info->in_new = 1;
+    if (len < 4) { info->terminal = QOA_DECODE_IO_ERROR; return QOA_OK; }
+    if (be32(bytes) != kMagic) { info->terminal = QOA_DECODE_NOT_QOA_FILE; return QOA_OK; }
+    if (len < 8) { info->terminal = QOA_DECODE_IO_ERROR; return QOA_OK; }
+    Walker w;
+    uint32_t s = be32(bytes + 4);
+    w.mode = s == 0 ? kStreaming : kFixed;
+    w.fixed_samples = s;
+    size_t pos = 8;
+    std::vector<FrameRec> frames;
+    int t = w.walk(bytes, len, &pos, frames);
+    info->mode.kind = w.mode == kStreaming ? QOA_MODE_STREAMING : QOA_MODE_FIXED_SAMPLES;
+    info->mode.channels = w.fixed_channels;
+    info->mode.sample_rate = w.fixed_rate;
+    info->mode.samples = s;
+    if (w.mode == kFixed && frames.empty()) { // the first frame is parsed inside QoaDecoder::new
+        info->terminal = t == kTermEnd ? QOA_DECODE_NO_SAMPLES : t;
+        return QOA_OK;
+    }
+    info->in_new = 0;
+    info->terminal = t;
+    info->n_frames = frames.size();
+    for (auto &f : frames) info->n_samples += (uint64_t)f.n_out * f.channels;
+    return QOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch decode plan
+// ------------------------------------------------------------------------------------------------
+struct qoa_decode_plan {
+    DevBuf chains, mismatch;
+    unsigned n = 0;
+    uint64_t in_bytes = 0, pcm_bytes = 0, samples = 0;
+};
+
+static int plan_upload(qoa_decode_plan *plan, const std::vector<DecChain> &chains) {
+    plan->n = (unsigned)chains.size();
+    HIP_TRY(plan->chains.reserve(chains.size() * sizeof(DecChain)), QOA_DECODE_IO_ERROR);
+    HIP_TRY(plan->mismatch.reserve(sizeof(unsigned)), QOA_DECODE_IO_ERROR);
+    if (!chains.empty())
+        HIP_TRY(hipMemcpy(plan->chains.p, chains.data(), chains.size() * sizeof(DecChain), hipMemcpyHostToDevice),
+                QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemset(plan->mismatch.p, 0, sizeof(unsigned)), QOA_DECODE_IO_ERROR);
+    return QOA_OK;
+}
+
+extern "C" int qoa_decode_plan_from_streams(const uint8_t *const *streams, const size_t *len, const uint64_t *in_offset,
+                                            const uint64_t *out_offset, size_t n_streams, int *status,
+                                            uint64_t *samples_out, qoa_decode_plan **out) {
+    if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
+    *out = nullptr;
+    std::vector<DecChain> chains;
+    uint64_t in_bytes = 0, samples = 0;
+    for (size_t i = 0; i < n_streams; i++) {
+        int st = QOA_OK;
+        uint64_t n_i16 = 0;
+        const uint8_t *d = streams[i];
+        size_t n = len[i];
+        if (in_offset[i] % 8 != 0) return fail_msg("in_offset must be 8-byte aligned", QOA_DECODE_IO_ERROR);
+        if (n < 4) st = QOA_DECODE_IO_ERROR;
+        else if (be32(d) != kMagic) st = QOA_DECODE_NOT_QOA_FILE;
+        else if (n < 8) st = QOA_DECODE_IO_ERROR;
+        else {
+            Walker w;
+            uint32_t s = be32(d + 4);
+            w.mode = s == 0 ? kStreaming : kFixed;
+            w.fixed_samples = s;
+            size_t pos = 8;
+            std::vector<FrameRec> frames;
+            st = w.walk(d, n, &pos, frames);
+            if (w.mode == kFixed && frames.empty() && st == kTermEnd) st = QOA_DECODE_NO_SAMPLES;
+            frames_to_chains(frames, 0, in_offset[i], out_offset[i], false, chains, &n_i16);
+        }
+        if (status) status[i] = st;
+        if (samples_out) samples_out[i] = n_i16;
+        in_bytes += n;
+        samples += n_i16;
+    }
+    auto *plan = new (std::nothrow) qoa_decode_plan();
+    if (!plan) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+    plan->in_bytes = in_bytes;
+    plan->samples = samples;
+    plan->pcm_bytes = samples * 2;
+    int rc = plan_upload(plan, chains);
+    if (rc) { delete plan; return rc; }
+    *out = plan;
+    return QOA_OK;
+}
+
+extern "C" int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips, qoa_decode_plan **out) {
+    if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
+    *out = nullptr;
+    std::vector<DecChain> chains;
+    uint64_t in_bytes = 0, samples = 0;
+    for (size_t i = 0; i < n_clips; i++) {
+        const qoa_desc &d = clips[i].desc;
+        if (validate_desc(&d)) return fail_msg("invalid qoa_desc in decode plan", QOA_DECODE_INVALID_FRAME_HEADER);
+        if (clips[i].out_offset % 8 != 0) return fail_msg("encoded offset must be 8-byte aligned", QOA_DECODE_IO_ERROR);
+        uint64_t pos = clips[i].out_offset + 8, outp = clips[i].pcm_offset;
+        uint32_t left = d.samples;
+        while (left > 0) {
+            uint32_t fl = std::min<uint32_t>(left, kFrameLen);
+            uint32_t rows = (fl + kSliceLen - 1) / kSliceLen;
+            uint32_t fsize = qoa_frame_size(d.channels, rows);
+            for (unsigned c = 0; c < d.channels; c++) {
+                DecChain dc;
+                dc.frame_off = pos;
+                dc.out_off = outp + c;
+                dc.n_out = fl;
+                dc.rows = (uint16_t)rows;
+                dc.channels = d.channels;
+                dc.channel = (uint8_t)c;
+                dc.expect_hi = ((uint32_t)d.channels << 24) | d.sample_rate;
+                dc.expect_lo = (fl << 16) | fsize;
+                chains.push_back(dc);
+            }
+            pos += fsize;
+            outp += (uint64_t)fl * d.channels;
+            left -= fl;
+        }
+        in_bytes += qoa_encoded_size(d.channels, d.samples);
+        samples += (uint64_t)d.samples * d.channels;
+    }
+    auto *plan = new (std::nothrow) qoa_decode_plan();
+    if (!plan) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+    plan->in_bytes = in_bytes;
+    plan->samples = samples;
+    plan->pcm_bytes = samples * 2;
+    int rc = plan_upload(plan, chains);
+    if (rc) { delete plan; return rc; }
+    *out = plan;
+    return QOA_OK;
+}
+
+extern "C" void qoa_decode_plan_free(qoa_decode_plan *plan) { delete plan; }
+
+extern "C" int qoa_decode_plan_bytes(const qoa_decode_plan *plan, uint64_t *in_bytes, uint64_t *pcm_bytes,
+                                     uint64_t *samples_i16) {
+    if (!plan) return fail_msg("null plan", QOA_DECODE_IO_ERROR);
+    if (in_bytes) *in_bytes = plan->in_bytes;
+    if (pcm_bytes) *pcm_bytes = plan->pcm_bytes;
+    if (samples_i16) *samples_i16 = plan->samples;
+    return QOA_OK;
+}
+
+extern "C" int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream) {
+    if (!plan) return fail_msg("null plan", QOA_DECODE_IO_ERROR);
+    HIP_TRY(launch_decode(d_in, d_out, (const DecChain *)plan->chains.p, plan->n, (unsigned *)plan->mismatch.p,
+                          (hipStream_t)stream),
+            QOA_DECODE_IO_ERROR);
+    return QOA_OK;
+}
+
+extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count) {
+    if (!plan || !count) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(count, plan->mismatch.p, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
+    return QOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QoaDecoder handle
+// ------------------------------------------------------------------------------------------------
+struct qoa_decoder {
+    std::vector<uint8_t> data; // the reader: Cursor<Vec<u8>>
+    size_t pos = 0;
+    Walker w;
+    std::vector<FrameRec> frames;
+    std::vector<size_t> frame_pcm; // start of each frame's samples in `pcm`
+    std::vector<int16_t> pcm;
+    int terminal = kTermEnd;       // what ends the iteration over the bytes seen so far
+    // iterator state (src/lib.rs:59-68, :668-692)
+    bool returned_first = false;
+    size_t it_frame = 0;           // next frame whose header/samples are to be emitted
+    bool it_header_done = false;   // header of frames[it_frame] already emitted
+    size_t it_sample = 0;          // next sample inside frames[it_frame]
+    bool finished_err = false;
+    qoa_frame_header current{};    // CurrentFrame.header, :283-286
+    hipStream_t stream = nullptr;
+    DevBuf d_in, d_out, d_chains, d_mismatch;
+    ~qoa_decoder() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+// Decode frames [first_frame, end) on the GPU and append their PCM to dec->pcm.
+static int decoder_decode_new_frames(qoa_decoder *dec, size_t first_frame) {
+    std::vector<DecChain> chains;
+    uint64_t n_i16 = 0;
+    frames_to_chains(dec->frames, first_frame, 0, 0, false, chains, &n_i16);
+    size_t base = dec->pcm.size();
+    {
+        size_t off = base;
+        for (size_t i = first_frame; i < dec->frames.size(); i++) {
+            dec->frame_pcm.push_back(off);
+            off += (size_t)dec->frames[i].n_out * dec->frames[i].channels;
+        }
+    }
+    dec->pcm.resize(base + n_i16);
+    if (chains.empty() || n_i16 == 0) return QOA_OK;
+    if (!dec->stream) HIP_TRY(hipStreamCreateWithFlags(&dec->stream, hipStreamNonBlocking), QOA_DECODE_IO_ERROR);
+    // upload only the byte range the new frames span
+    size_t lo = dec->frames[first_frame].pos & ~(size_t)3, hi = dec->data.size();
+    for (auto &c : chains) c.frame_off -= lo;
+    HIP_TRY(dec->d_in.reserve(hi - lo + 8), QOA_DECODE_IO_ERROR);
+    HIP_TRY(dec->d_out.reserve(n_i16 * 2), QOA_DECODE_IO_ERROR);
+    HIP_TRY(dec->d_chains.reserve(chains.size() * sizeof(DecChain)), QOA_DECODE_IO_ERROR);
+    HIP_TRY(dec->d_mismatch.reserve(sizeof(unsigned)), QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemcpyAsync(dec->d_in.p, dec->data.data() + lo, hi - lo, hipMemcpyHostToDevice, dec->stream),
+            QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemcpyAsync(dec->d_chains.p, chains.data(), chains.size() * sizeof(DecChain), hipMemcpyHostToDevice,
+                           dec->stream),
+            QOA_DECODE_IO_ERROR);
+    HIP_TRY(launch_decode((const uint8_t *)dec->d_in.p, (int16_t *)dec->d_out.p, (const DecChain *)dec->d_chains.p,
+                          (unsigned)chains.size(), (unsigned *)dec->d_mismatch.p, dec->stream),
+            QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemcpyAsync(dec->pcm.data() + base, dec->d_out.p, n_i16 * 2, hipMemcpyDeviceToHost, dec->stream),
+            QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipStreamSynchronize(dec->stream), QOA_DECODE_IO_ERROR);
+    return QOA_OK;
+}
+
+// Walk whatever bytes are unread, decode the frames found.  Returns 0 or a HIP failure code.
+static int decoder_advance(qoa_decoder *dec) {
+    size_t first_new = dec->frames.size();
+    dec->terminal = dec->w.walk(dec->data.data(), dec->data.size(), &dec->pos, dec->frames);
+    return decoder_decode_new_frames(dec, first_new);
+}
+
+extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **out) { // src/lib.rs:127-169
+    if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
+    *out = nullptr;
+    if (len < 4) return fail_msg("failed to fill whole buffer", QOA_DECODE_IO_ERROR); // read_u32_be -> UnexpectedEof
+    if (be32(bytes) != kMagic) return QOA_DECODE_NOT_QOA_FILE;
+    if (len < 8) return fail_msg("failed to fill whole buffer", QOA_DECODE_IO_ERROR);
+    auto *dec = new (std::nothrow) qoa_decoder();
+    if (!dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+    dec->data.assign(bytes, bytes + len);
+    dec->pos = 8;
+    uint32_t samples = be32(bytes + 4);
+    dec->w.mode = samples == 0 ? kStreaming : kFixed;
+    dec->w.fixed_samples = samples;
+    int rc = decoder_advance(dec);
+    if (rc) { delete dec; return rc; }
+    if (dec->w.mode == kFixed) {
+        // the first frame header + LMS are parsed inside new(): its errors are new()'s errors (:161-166)
+        if (dec->frames.empty()) {
+            int t = dec->terminal;
+            delete dec;
+            if (t == kTermEnd) return QOA_DECODE_NO_SAMPLES;
+            if (t == QOA_DECODE_IO_ERROR) g_detail = "failed to fill whole buffer";
+            return t;
+        }
+        dec->current.num_channels = dec->frames[0].channels;
+        dec->current.sample_rate = dec->frames[0].rate;
+        dec->current.num_samples_per_channel = dec->frames[0].nspc;
+    }
+    *out = dec;
+    return QOA_OK;
+}
+
+extern "C" int qoa_decoder_new_streaming(qoa_decoder **out) { // src/lib.rs:632-638
+    static const uint8_t hdr[8] = {'q', 'o', 'a', 'f', 0, 0, 0, 0};
+    return qoa_decoder_new(hdr, 8, out);
+}
+
+extern "C" void qoa_decoder_free(qoa_decoder *dec) { delete dec; }
+
+extern "C" int qoa_decoder_mode(const qoa_decoder *dec, qoa_mode *mode) {
+    if (!dec || !mode) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    mode->kind = dec->w.mode == kStreaming ? QOA_MODE_STREAMING : QOA_MODE_FIXED_SAMPLES;
+    mode->channels = dec->w.fixed_channels;
+    mode->sample_rate = dec->w.fixed_rate;
+    mode->samples = dec->w.fixed_samples;
+    return QOA_OK;
+}
+
+extern "C" int qoa_decoder_current_frame_header(const qoa_decoder *dec, qoa_frame_header *h) {
+    if (!dec || !h) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    *h = dec->current;
+    return QOA_OK;
+}
+
+extern "C" double qoa_decoder_total_duration(const qoa_decoder *dec) { // src/lib.rs:190-201
+    if (!dec || dec->w.mode == kStreaming) return -1.0;
+    return (double)dec->w.fixed_samples / (double)dec->w.fixed_rate;
+}
+
+// Iterator::next (src/lib.rs:668-692) replayed over the pre-decoded frames.
+extern "C" int qoa_decoder_next(qoa_decoder *dec, qoa_item *item) {
+    if (!dec || !item) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    memset(item, 0, sizeof *item);
+    if (dec->finished_err) { item->kind = QOA_ITEM_END; return QOA_OK; }
+    for (;;) {
+        bool have = dec->it_frame < dec->frames.size();
+        // pending samples of the current frame come first (:669-673)
+        if (have && dec->it_header_done) {
+            const FrameRec &f = dec->frames[dec->it_frame];
+            size_t n = (size_t)f.n_out * f.channels;
+            if (dec->it_sample < n) {
+                item->kind = QOA_ITEM_SAMPLE;
+                item->sample = dec->pcm[dec->frame_pcm[dec->it_frame] + dec->it_sample++];
+                return QOA_OK;
+            }
+        }
+        if (!dec->returned_first) { // :674-678 -- the header parsed in new(), or the zero default in streaming mode
+            dec->returned_first = true;
+            item->kind = QOA_ITEM_FRAME_HEADER;
+            item->header = dec->current;
+            if (dec->w.mode == kFixed) dec->it_header_done = true; // frame 0's header is this item
+            return QOA_OK;
+        }
+        if (have && dec->it_header_done) { // frame exhausted: move on
+            dec->it_frame++;
+            dec->it_header_done = false;
+            dec->it_sample = 0;
+            continue;
+        }
+        if (have) { // next frame header (:684-685)
+            const FrameRec &f = dec->frames[dec->it_frame];
+            dec->current.num_channels = f.channels;
+            dec->current.sample_rate = f.rate;
+            dec->current.num_samples_per_channel = f.nspc;
+            dec->it_header_done = true;
+            item->kind = QOA_ITEM_FRAME_HEADER;
+            item->header = dec->current;
+            return QOA_OK;
+        }
+        if (dec->terminal == kTermEnd) { item->kind = QOA_ITEM_END; return QOA_OK; } // :686
+        item->kind = QOA_ITEM_ERROR;
+        item->error = dec->terminal;
+        if (dec->terminal == QOA_DECODE_IO_ERROR) g_detail = "failed to fill whole buffer";
+        dec->finished_err = true;
+        return QOA_OK;
+    }
+}
+
+extern "C" size_t qoa_decoder_read_samples(qoa_decoder *dec, int16_t *out, size_t cap) {
+    if (!dec || !out || dec->finished_err) return 0;
+    if (!(dec->it_frame < dec->frames.size() && dec->it_header_done)) return 0;
+    const FrameRec &f = dec->frames[dec->it_frame];
+    size_t n = (size_t)f.n_out * f.channels;
+    size_t take = std::min(cap, n - dec->it_sample);
+    if (take) memcpy(out, dec->pcm.data() + dec->frame_pcm[dec->it_frame] + dec->it_sample, take * sizeof(int16_t));
+    dec->it_sample += take;
+    return take;
+}
+
+extern "C" int qoa_decoder_decode_frame(qoa_decoder *dec, const uint8_t *frame, size_t len, int16_t *out, size_t cap,
+                                        size_t *n_out) { // src/lib.rs:641-651
+    if (!dec) return fail_msg("null decoder", QOA_DECODE_IO_ERROR);
+    if (dec->finished_err) { if (n_out) *n_out = 0; return QOA_OK; }
+    if (len) {
+        dec->data.insert(dec->data.end(), frame, frame + len);
+        int rc = decoder_advance(dec);
+        if (rc) return rc;
+    }
+    // drain the iterator: count first, so that a too-small buffer loses nothing
+    size_t total = 0;
+    {
+        size_t fi = dec->it_frame;
+        bool hd = dec->it_header_done;
+        size_t si = dec->it_sample;
+        for (; fi < dec->frames.size(); fi++, hd = false, si = 0) {
+            (void)hd;
+            total += (size_t)dec->frames[fi].n_out * dec->frames[fi].channels - si;
+        }
+    }
+    if (n_out) *n_out = total;
+    if (!out || cap < total) {
+        if (total == 0 && dec->terminal != kTermEnd) { dec->finished_err = true; return dec->terminal; }
+        return total ? fail_msg("output buffer too small; call again with len == 0", QOA_DECODE_IO_ERROR) : QOA_OK;
+    }
+    size_t w = 0;
+    qoa_item it;
+    for (;;) {
+        qoa_decoder_next(dec, &it);
+        if (it.kind == QOA_ITEM_END) break;
+        if (it.kind == QOA_ITEM_ERROR) return it.error; // `item?` -- samples gathered so far are dropped
+        if (it.kind == QOA_ITEM_SAMPLE) {
+            out[w++] = it.sample;
+            w += qoa_decoder_read_samples(dec, out + w, cap - w);
+        }
+    }
+    return QOA_OK;
+}
+
+extern "C" int qoa_decode_all(const uint8_t *bytes, size_t len, uint8_t *channels, uint32_t *sample_rate, int16_t *out,
+                              size_t cap, size_t *n_out) { // src/lib.rs:713-747
+    qoa_decoder *dec = nullptr;
+    int rc = qoa_decoder_new(bytes, len, &dec);
+    if (rc) return rc;
+    qoa_item it;
+    qoa_decoder_next(dec, &it); // always the first FrameHeader (:724-731)
+    uint8_t nch = it.header.num_channels;
+    uint32_t sr = it.header.sample_rate;
+    size_t n = 0;
+    for (;;) {
+        qoa_decoder_next(dec, &it);
+        if (it.kind == QOA_ITEM_END) break;
+        if (it.kind == QOA_ITEM_ERROR) { rc = it.error; break; }
+        if (it.kind == QOA_ITEM_SAMPLE) {
+            if (out && n < cap) out[n] = it.sample;
+            n++;
+            if (out && n < cap) n += qoa_decoder_read_samples(dec, out + n, cap - n);
+            else {
+                // count-only pass: skip the rest of this frame
+                int16_t tmp[256];
+                size_t k;
+                while ((k = qoa_decoder_read_samples(dec, tmp, 256)) != 0) n += k;
+            }
+        } else if (it.header.num_channels != nch || it.header.sample_rate != sr) { // :735-738
+            rc = QOA_DECODE_INCOMPATIBLE_FRAME;
+            break;
+        }
+    }
+    qoa_decoder_free(dec);
+    if (rc) return rc;
+    if (channels) *channels = nch;
+    if (sample_rate) *sample_rate = sr;
+    if (n_out) *n_out = n;
+    return QOA_OK;
+}

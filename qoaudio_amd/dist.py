@@ -1,0 +1,76 @@
+"""Clip sharding across the GPUs of one node (BASELINE config 4).
+
+Clips are fully independent units, so a batch shards with NO data-path collective: rank r encodes a
+contiguous block of clips on its own GPU.  The one exchange step the config names is the gather of the
+fixed-size encoded buffers (encoded size is a pure function of the desc, src/lib.rs:374-378, so every
+offset is known a priori): rank 0 receives each peer's shard over that peer's own xGMI link
+(torch.distributed `gather` = grouped RCCL send/recv; backend "nccl" is RCCL on ROCm).  The same code
+runs over gloo on CPU tensors, which is how tests/test_dist_gloo.py covers the N>1 path.
+"""
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition; the first n_items % world ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def init_from_env(backend: Optional[str] = None):
+    """One process per GPU, launched by torch.distributed.run.  Returns (rank, world, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def gather_encoded(local: torch.Tensor, n_total: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Gather every rank's [n_local, per_enc] uint8 shard (block partition of n_total clips, see shard_range)
+    into [n_total, per_enc] on rank `dst`; other ranks return None."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per_enc = local.shape[1]
+    counts = [shard_range(n_total, r, world) for r in range(world)]
+    assert local.shape[0] == counts[rank][1] - counts[rank][0], "shard does not match shard_range()"
+    n_max = max(b - a for a, b in counts)
+    send = local
+    if local.shape[0] != n_max:  # uneven tail: pad to the common size, trimmed again on dst
+        send = torch.zeros((n_max, per_enc), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    if rank == dst:
+        parts = [torch.empty((n_max, per_enc), dtype=local.dtype, device=local.device) for _ in range(world)]
+        dist.gather(send.contiguous(), gather_list=parts, dst=dst, group=group)
+        out = torch.empty((n_total, per_enc), dtype=local.dtype, device=local.device)
+        for r, (a, b) in enumerate(counts):
+            out[a:b] = parts[r][: b - a]
+        return out
+    dist.gather(send.contiguous(), gather_list=None, dst=dst, group=group)
+    return None
+
+
+def barrier_max_ms(elapsed_ms: float, device) -> float:
+    """MAX over ranks of a per-rank elapsed time (bench.py's timing rule)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return elapsed_ms
+    t = torch.tensor([elapsed_ms], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FIXTURE = os.path.join(GOLDEN, "julien_baker_sprained_ankle.qoa")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fixture_bytes():
+    with open(FIXTURE, "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def fixture_pcm(oracle, fixture_bytes):
+    ch, sr, pcm = oracle.decode_all(fixture_bytes)
+    assert (ch, sr, pcm.size) == (2, 44100, 2394122 * 2)
+    return pcm
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product package on a real device; fails loudly if the HIP extension is not there."""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    import qoaudio_amd
+    from qoaudio_amd import _lib
+    _lib.lib()
+    return qoaudio_amd
+
+
+def rng_pcm(seed, n, kind="mix"):
+    """Deterministic int16 test signals (numpy only; values are shared by GPU path and oracle)."""
+    r = np.random.default_rng(seed)
+    if kind == "white":
+        return r.integers(-32768, 32768, n, dtype=np.int64).astype(np.int16)
+    if kind == "loud":  # +-full-scale alternation with noise: exercises qoa_div's wrapping case
+        x = np.where(np.arange(n) % 2 == 0, 32767, -32768) + r.integers(-3, 4, n)
+        return np.clip(x, -32768, 32767).astype(np.int16)
+    if kind == "silence":
+        return np.zeros(n, dtype=np.int16)
+    if kind == "square":
+        return (np.where((np.arange(n) // 37) % 2 == 0, 12000, -12000)).astype(np.int16)
+    t = np.arange(n)
+    x = 6000 * np.sin(t * 0.031) + 3000 * np.sin(t * 0.173 + 1.0) + 900 * np.sin(t * 0.71) + r.normal(0, 300, n)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)

@@ -1,0 +1,271 @@
+"""CPU-side checks of the product library: it loads, exports everything include/qoaudio_amd.h declares,
+its host logic (sizes, validation order, stream walking) agrees with the oracle, and -- without a GPU --
+its compute entry points fail loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rng_pcm
+
+HEADER = os.path.join(ROOT, "include", "qoaudio_amd.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from qoaudio_amd import _lib
+    return _lib.lib()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qoa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    from qoaudio_amd import _lib
+    decl = declared_functions()
+    assert len(decl) >= 30
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    for name in decl:
+        assert re.search(rf" T {name}\b", exported), f"{name} declared in qoaudio_amd.h but not exported"
+        getattr(L, name)
+    assert sorted(_lib.SYMBOLS) == decl, "qoaudio_amd/_lib.py SYMBOLS out of sync with the header"
+
+
+def test_library_has_gfx950_code_object():
+    from qoaudio_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"qoa_encode_kernel" in blob and b"qoa_decode_kernel" in blob
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under qoaudio_amd/ may import, link or call it."""
+    from qoaudio_amd import _lib
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "qoaudio_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                for needle in ("import oracle", "from oracle", "liboracle", "oq_", "oracle/", "oracle.py"):
+                    assert needle not in text, (f, needle)
+    assert b"oq_encode" not in open(_lib.LIB_PATH, "rb").read()
+
+
+def test_encoded_size_and_frame_size(L, oracle):
+    assert L.qoa_encoded_size(2, 2394122) == 1934040  # the fixture's length, src/lib.rs:374-378
+    assert L.qoa_encoded_size(1, 1310720) == 530440 and L.qoa_encoded_size(2, 1310720) == 1058824
+    for ch in range(1, 9):
+        for n in (1, 19, 20, 21, 5119, 5120, 5121, 1310720, 28800000):
+            assert L.qoa_encoded_size(ch, n) == oracle.encoded_size(ch, n)
+        for slices in (1, 2, 255, 256):
+            assert L.qoa_frame_size(ch, slices) == 8 + 16 * ch + 8 * slices * ch
+    assert L.qoa_frame_size(8, 256) == 16520
+
+
+def test_validation_order_without_touching_the_gpu(L):
+    from qoaudio_amd import EncodeError, QoaDesc, QoaEncoder
+    for desc, kind in ((QoaDesc(0, 44100, 1000), "InvalidChannels"), (QoaDesc(9, 44100, 1000), "InvalidChannels"),
+                       (QoaDesc(1, 0, 1000), "InvalidSampleRate"), (QoaDesc(1, 44100, 0), "InvalidSamples"),
+                       (QoaDesc(0, 0, 0), "InvalidChannels"), (QoaDesc(8, 0, 0), "InvalidSampleRate")):
+        with pytest.raises(EncodeError) as e:
+            QoaEncoder(desc)
+        assert e.value.kind == kind
+    assert str(EncodeError(1)) == "Invalid number of channels (must be 1-8)"  # src/lib.rs:900-902
+    assert str(EncodeError(2)) == "Invalid sample rate (must be > 0)"
+    assert str(EncodeError(3)) == "Invalid number of samples (must be > 0)"
+
+
+def test_decode_error_strings(L):
+    from qoaudio_amd import DecodeError
+    assert str(DecodeError(1)) == "File is not a qoa file"  # src/lib.rs:880-883
+    assert str(DecodeError(2)) == "File has no samples"
+    assert str(DecodeError(3)) == "File has invalid frame header"
+    assert str(DecodeError(4)) == "Incompatible frame header"
+    assert str(DecodeError(5)).startswith("IO error: ")
+
+
+def test_plan_validation(L):
+    from qoaudio_amd import EncodeError, QoaDesc
+    from qoaudio_amd import batch
+    with pytest.raises(EncodeError) as e:
+        batch.EncodePlan([(0, 0, QoaDesc(2, 44100, 100)), (200, 1000, QoaDesc(0, 44100, 100))])
+    assert e.value.kind == "InvalidChannels"
+    with pytest.raises(EncodeError) as e:
+        batch.EncodePlan([(0, 4, QoaDesc(2, 44100, 100))])  # out_offset not 8-byte aligned
+    assert e.value.kind == "IoError"
+
+
+def test_no_gpu_means_loud_io_error(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    from qoaudio_amd import DecodeError, EncodeError, QoaDesc, encode_all, decode_all
+    with pytest.raises(EncodeError) as e:
+        encode_all(np.zeros(100, np.int16), QoaDesc(1, 44100, 100))
+    assert e.value.kind == "IoError" and "IO error: " in str(e.value)
+
+
+def scan(L, data):
+    from qoaudio_amd import _lib
+    info = _lib.StreamInfo()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    rc = L.qoa_stream_scan(buf.ctypes.data_as(C.c_void_p) if buf.size else None, buf.size, C.byref(info))
+    assert rc == 0
+    return info
+
+
+def oracle_walk(oracle, data):
+    """(error raised by new or None, terminal error or None, #FrameHeader items, #Sample items) per the oracle."""
+    try:
+        dec = oracle.OracleDecoder(data)
+    except oracle.OracleError as e:
+        return e.kind, None, 0, 0
+    streaming = dec.mode() == ("Streaming",)
+    frames = samples = 0
+    term = None
+    first = True
+    for kind, val in dec:
+        if kind == "Sample":
+            samples += 1
+        elif kind == "FrameHeader":
+            if first and streaming:
+                assert val == (0, 0, 0)  # the default header, src/lib.rs:146-147,:674-678
+            else:
+                frames += 1
+        else:
+            term = val
+        first = False
+    return None, term, frames, samples
+
+
+ERR = {0: None, 1: "NotQoaFile", 2: "NoSamples", 3: "InvalidFrameHeader", 4: "IncompatibleFrame", 5: "IoError"}
+
+
+def check_scan(L, oracle, data):
+    info = scan(L, data)
+    new_err, term, frames, samples = oracle_walk(oracle, data)
+    if new_err is not None:
+        assert info.in_new == 1 and ERR[info.terminal] == new_err, (new_err, info.terminal)
+    else:
+        assert info.in_new == 0
+        assert ERR[info.terminal] == term
+        assert (info.n_frames, info.n_samples) == (frames, samples)
+
+
+def test_stream_scan_matches_reference_reader_on_truncations(L, oracle):
+    x = rng_pcm(11, 5200 * 2)
+    enc = oracle.encode_all(x, 2, 32000, 5200)  # two frames: 5120 + 80 sample-times
+    for cut in list(range(0, 80)) + list(range(len(enc) - 140, len(enc) + 1)) + [4136 + 8 + k for k in range(-9, 60)]:
+        check_scan(L, oracle, enc[:cut])
+    check_scan(L, oracle, enc + b"\0" * 5)  # trailing partial header bytes = clean EOF
+    check_scan(L, oracle, enc + enc[8:])    # concatenated frames keep decoding
+
+
+def test_stream_scan_matches_reference_reader_on_bad_headers(L, oracle):
+    x = rng_pcm(12, 300 * 3)
+    enc = bytearray(oracle.encode_all(x, 3, 8000, 300))
+    def patched(off, val):
+        b = bytearray(enc)
+        b[off:off + len(val)] = val
+        return bytes(b)
+    cases = [
+        patched(8, b"\0"),                    # channels = 0
+        patched(9, b"\0\0\0"),                # sample rate = 0
+        patched(14, (8 + 48).to_bytes(2, "big")),   # frame_size <= header + lms
+        patched(14, (8 + 48 + 8 * 4).to_bytes(2, "big")),  # slices not a multiple of channels
+        patched(14, (8 + 16 + 8 * 257).to_bytes(2, "big")),  # > 256 slices per channel (with ch patched below)
+        patched(12, (100).to_bytes(2, "big")),   # fewer samples than the slices present: reader resyncs early
+        patched(12, (320).to_bytes(2, "big")),   # more samples than slices present: runs into EOF
+        patched(4, b"\0\0\0\0"),              # samples = 0 -> streaming mode
+        patched(0, b"QOAF"),
+    ]
+    cases.append(bytes(enc) + patched(8, b"\2")[8:])     # second frame with different channel count (fixed mode)
+    cases.append(patched(4, b"\0\0\0\0") + patched(8, b"\1")[8:60])  # streaming mode, channel change, then cut
+    for c in cases:
+        check_scan(L, oracle, c)
+
+
+def test_stream_scan_random_corruption(L, oracle):
+    r = np.random.default_rng(99)
+    x = rng_pcm(13, 700 * 2)
+    enc = oracle.encode_all(x, 2, 44100, 700)
+    for _ in range(300):
+        b = bytearray(enc)
+        for _ in range(int(r.integers(1, 4))):
+            b[int(r.integers(0, 64))] = int(r.integers(0, 256))  # headers live in the first bytes
+        cut = int(r.integers(0, len(b) + 1)) if r.random() < 0.5 else len(b)
+        check_scan(L, oracle, bytes(b[:cut]))
+
+
+def test_streaming_decoder_handle_without_frames_needs_no_gpu(L):
+    from qoaudio_amd import FrameHeader, QoaDecoder, Streaming, DecodeError
+    d = QoaDecoder.new_streaming()
+    assert d.mode() == Streaming()
+    assert d.total_duration() is None
+    assert d.next() == FrameHeader(0, 0, 0)  # the default header comes first in streaming mode
+    assert d.next() is None
+    for data, kind in ((b"", "IoError"), (b"qoa", "IoError"), (b"riff0000", "NotQoaFile"),
+                       (b"qoaf\0\0\0\1", "NoSamples"), (b"qoaf\0\0\0\1" + bytes(8), "InvalidFrameHeader")):
+        with pytest.raises(DecodeError) as e:
+            QoaDecoder(data)
+        assert e.value.kind == kind
+
+
+# ---- the kernel's arithmetic identities, checked exhaustively on the CPU ----
+
+QUANT_TAB = np.array([7, 7, 7, 5, 5, 3, 3, 1, 0, 0, 2, 2, 4, 4, 6, 6, 6])
+RECIP = np.array([65536, 9363, 3121, 1457, 781, 475, 311, 216, 156, 117, 90, 71, 57, 47, 39, 32])
+DEQUANT = np.array([[1, -1, 3, -3, 5, -5, 7, -7], [5, -5, 18, -18, 32, -32, 49, -49],
+                    [16, -16, 53, -53, 95, -95, 147, -147], [34, -34, 113, -113, 203, -203, 315, -315],
+                    [63, -63, 210, -210, 378, -378, 588, -588], [104, -104, 345, -345, 621, -621, 966, -966],
+                    [158, -158, 528, -528, 950, -950, 1477, -1477], [228, -228, 760, -760, 1368, -1368, 2128, -2128],
+                    [316, -316, 1053, -1053, 1895, -1895, 2947, -2947], [422, -422, 1405, -1405, 2529, -2529, 3934, -3934],
+                    [548, -548, 1828, -1828, 3290, -3290, 5117, -5117], [696, -696, 2320, -2320, 4176, -4176, 6496, -6496],
+                    [868, -868, 2893, -2893, 5207, -5207, 8099, -8099], [1064, -1064, 3548, -3548, 6386, -6386, 9933, -9933],
+                    [1286, -1286, 4288, -4288, 7718, -7718, 12005, -12005],
+                    [1536, -1536, 5120, -5120, 9216, -9216, 14336, -14336]])
+
+
+def test_kernel_quantiser_closed_form_is_exact_for_every_residual():
+    """qoa_kernels.hip replaces the QUANT/DEQUANT table lookups (src/lib.rs:569-572) by
+    level = min(|scaled|,7)&6, code = level - (scaled>>31), dequant = +-mag[level/2], with the products
+    taken on the 24-bit multiplier.  Checked for EVERY residual the encoder can see and all 16 scalefactors
+    (|residual| <= 32767 + 2^18, incl. the i32 wrap of qoa_div at sf 0/1, src/lib.rs:613-617)."""
+    res = np.arange(-(2 ** 18) - 32768, 2 ** 18 + 32768 + 1, dtype=np.int64)
+    sext24 = lambda v: ((v + 2 ** 23) % 2 ** 24) - 2 ** 23
+    wrap32 = lambda v: ((v + 2 ** 31) % 2 ** 32) - 2 ** 31
+    for sf in range(16):
+        # reference formulation
+        n = wrap32(wrap32(res * RECIP[sf]) + 32768) >> 16
+        scaled = n + np.sign(res) - np.sign(n)
+        c = np.clip(scaled, -8, 8)
+        code_ref = QUANT_TAB[c + 8]
+        deq_ref = DEQUANT[sf][code_ref]
+        # kernel formulation
+        n_k = wrap32(sext24(res) * sext24(RECIP[sf]) + 32768) >> 16   # v_mad_i32_i24: low 32 bits of the 48-bit product
+        scaled_k = n_k + np.clip(res, -1, 1) - np.clip(n_k, -1, 1)     # v_med3_i32
+        sneg = scaled_k >> 31
+        a = (scaled_k ^ sneg) - sneg
+        l2 = np.minimum(a, 7) & 6
+        mag = DEQUANT[sf][l2]                                           # v_perm_b32 over the 4 packed magnitudes
+        deq_k = (mag ^ sneg) - sneg
+        code_k = l2 - sneg
+        assert np.array_equal(code_ref, code_k), sf
+        assert np.array_equal(deq_ref, deq_k), sf
+
+
+def test_mul24_equals_wrapping_mul_inside_the_guard():
+    """v_mul_i32_i24 returns the low 32 bits of sext24(a)*sext24(b): equal to the wrapping i32 product for
+    every operand pair the fast path can produce (|w| < 2^23 at all 20 steps, |h| <= 2^15)."""
+    r = np.random.default_rng(7)
+    lim = 2 ** 23 - 20 * 896
+    w = np.concatenate([r.integers(-lim - 17920, lim + 17920, 200000), [lim + 17919, -lim - 17919, 0, 1, -1]])
+    h = np.concatenate([r.integers(-32768, 32768, 200000), [-32768, 32767, 0, 1, -1]])
+    wrap32 = lambda v: ((v + 2 ** 31) % 2 ** 32) - 2 ** 31
+    sext24 = lambda v: ((v + 2 ** 23) % 2 ** 24) - 2 ** 23
+    assert np.array_equal(wrap32(w * h), wrap32(sext24(w) * sext24(h)))
+    assert np.array_equal(wrap32(w * w), wrap32(sext24(w) * sext24(w)))

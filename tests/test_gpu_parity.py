@@ -1,0 +1,321 @@
+"""Parity of the HIP path against the CPU oracle, bit for bit (integer work: no tolerance anywhere).
+Every call goes through the C ABI (qoaudio_amd/api.py and batch.py are ctypes over libqoaudio_amd.so)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rng_pcm
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [1, 2, 19, 20, 21, 39, 40, 41, 45, 319, 320, 321, 339, 5119, 5120, 5121, 5140, 10241]
+
+
+@pytest.mark.parametrize("channels", range(1, 9))
+def test_encode_all_matches_oracle(gpu, oracle, channels):
+    """fuzz-style inputs over the edge lengths SURVEY section 4 lists (1, 19/20/21, 5119/5120/5121, tails)."""
+    for n in LENGTHS:
+        for kind in ("mix", "white") if n > 100 else ("mix", "white", "loud", "square", "silence"):
+            x = rng_pcm(7919 * channels + n, n * channels, kind)
+            got = gpu.encode_all(x, gpu.QoaDesc(channels, 44100, n))
+            want = oracle.encode_all(x, channels, 44100, n)
+            assert got == want, (channels, n, kind)
+
+
+@pytest.mark.parametrize("channels", [1, 2, 5, 8])
+def test_decode_all_matches_oracle(gpu, oracle, channels):
+    for n in LENGTHS:
+        x = rng_pcm(31 * channels + n, n * channels, "mix")
+        enc = oracle.encode_all(x, channels, 48000, n)
+        d = gpu.decode_all(enc)
+        ch, sr, want = oracle.decode_all(enc)
+        assert (d.num_channels, d.sample_rate) == (ch, sr) == (channels, 48000)
+        assert np.array_equal(d.samples, want), (channels, n)
+        d2 = gpu.decode_all_capi(enc)
+        assert np.array_equal(d2.samples, want)
+
+
+def test_fixture_config1(gpu, oracle, fixture_bytes, fixture_pcm):
+    """BASELINE config 1: fixture -> PCM -> QOA.  KAT-3 (decoded PCM hash), KAT-1 (fixed-point prefix)."""
+    d = gpu.decode_all(fixture_bytes)
+    assert (d.num_channels, d.sample_rate, d.samples.size) == (2, 44100, 2394122 * 2)
+    assert hashlib.sha256(d.samples.astype("<i2").tobytes()).hexdigest() == \
+        "2ed7d9a42d13659a6ff51b04728499d99ac99686326b87f215fdeabe05522619"
+    assert np.array_equal(d.samples, fixture_pcm)
+    enc = gpu.encode_all(d.samples, gpu.QoaDesc(2, 44100, 2394122))
+    assert len(enc) == 1934040
+    assert enc[:1_073_768] == fixture_bytes[:1_073_768]
+    assert enc == oracle.encode_all(fixture_pcm, 2, 44100, 2394122)
+
+
+def test_loud_signals_hit_the_wrapping_divide(gpu, oracle):
+    """|residual| >= 32768 makes qoa_div wrap for scalefactor 0 (src/lib.rs:606-617): must match bit for bit."""
+    for seed in range(4):
+        x = rng_pcm(seed, 4000, "loud")
+        assert gpu.encode_all(x, gpu.QoaDesc(1, 44100, 4000)) == oracle.encode_all(x, 1, 44100, 4000)
+    x = np.tile(np.array([32767, -32768, -32768, 32767, 0, 32767], dtype=np.int16), 700)
+    assert gpu.encode_all(x, gpu.QoaDesc(2, 44100, 2100)) == oracle.encode_all(x, 2, 44100, 2100)
+
+
+def _oracle_with_state(oracle, channels, rate, samples, state):
+    e = oracle.OracleEncoder(channels, rate, samples)
+    for c in range(channels):
+        for i in range(4):
+            e.e.lms[c].history[i] = int(state[c][i])
+            e.e.lms[c].weights[i] = int(state[c][4 + i])
+    return e
+
+
+@pytest.mark.parametrize("big", [2 ** 23 - 20 * 896 - 1, 2 ** 23 - 20 * 896, 2 ** 23, 2 ** 24 + 12345, 2 ** 30, -2 ** 31])
+def test_huge_weights_take_the_generic_path(gpu, oracle, big):
+    """Weights are unbounded i32 in principle; beyond the 24-bit guard the kernel must switch to full
+    32-bit multiplies and still match the reference's wrapping arithmetic (src/lib.rs:800-816, :823-826)."""
+    channels, n = 2, 900
+    x = rng_pcm(big % 1000, n * channels, "mix")
+    state = np.zeros((channels, 8), dtype=np.int64)
+    state[0] = [100, -200, 300, -400, big, -big // 3, 77, -16384]
+    state[1] = [-5, 6, -7, 8, 5, big, -(big // 2), 3]
+    state = ((state + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.int32)
+    enc = gpu.QoaEncoder(gpu.QoaDesc(channels, 44100, n))
+    enc.set_lms_state(state)
+    fl, data = enc.encode_frame(x)
+    ref = _oracle_with_state(oracle, channels, 44100, n, state)
+    want, _ = ref.encode_frame(x)
+    assert fl == n and data == want
+    got_state = enc.lms_state()
+    want_state = np.array([h + w for h, w in ref.lms_state()], dtype=np.int32)
+    assert np.array_equal(got_state, want_state)
+
+
+def test_streaming_encode_equals_one_shot(gpu, oracle, fixture_pcm):
+    """src/lib.rs:1261-1297 on the first 12 frames of the fixture + a short tail frame; state is carried in
+    device memory as full i32 (never through the 16-bit header image)."""
+    n = 5120 * 12 + 777
+    pcm = fixture_pcm[: n * 2]
+    desc = gpu.QoaDesc(2, 44100, n)
+    oneshot = gpu.QoaEncoder(desc).encode(pcm)
+    enc = gpu.QoaEncoder(desc)
+    streamed = bytearray()
+    enc.write_header(streamed)
+    off = 0
+    while off < n:
+        fl = min(5120, n - off)
+        assert enc.encode_frame(pcm[off * 2:(off + fl) * 2], streamed) == fl
+        off += fl
+    assert bytes(streamed) == oneshot == oracle.encode_all(pcm, 2, 44100, n)
+    for bad in (np.zeros(0, np.int16), np.zeros(3, np.int16), np.zeros(5121 * 2, np.int16)):  # :424-430
+        with pytest.raises(gpu.EncodeError) as e:
+            enc.encode_frame(bad)
+        assert e.value.kind == "InvalidSamples"
+    with pytest.raises(gpu.EncodeError) as e:  # :368-370
+        gpu.QoaEncoder(desc).encode(pcm[:-2])
+    assert e.value.kind == "InvalidSamples"
+
+
+def test_config5_eight_channel_streaming(gpu, oracle):
+    """BASELINE config 5 in miniature: 8 channels, 48 kHz, frame-at-a-time, LMS carried across frames."""
+    frames, ch = 6, 8
+    n = 5120 * frames
+    x = rng_pcm(5, n * ch, "mix")
+    enc = gpu.QoaEncoder(gpu.QoaDesc(ch, 48000, n))
+    out = bytearray()
+    enc.write_header(out)
+    for f in range(frames):
+        _, data = enc.encode_frame(x[f * 5120 * ch:(f + 1) * 5120 * ch])
+        assert len(data) == 16520
+        out += data
+    assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
+
+
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic"])
+def test_ragged_batch_all_paths(gpu, oracle, flags):
+    """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
+    forced generic path must all produce the oracle's bytes."""
+    from qoaudio_amd import batch
+    fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
+          "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4}[flags]
+    shapes = [(2, 5300), (1, 41), (2, 20), (3, 999), (2, 12000), (1, 6000), (8, 333), (2, 1), (1, 5120), (2, 5121),
+              (5, 777), (2, 640), (1, 10240), (2, 319)]
+    clips, pcm_parts, pcm_off, out_off = [], [], 0, 0
+    for i, (ch, n) in enumerate(shapes):
+        x = rng_pcm(100 + i, n * ch, "mix" if i % 3 else "white")
+        pcm_parts.append(x)
+        clips.append((pcm_off, out_off, gpu.QoaDesc(ch, 44100 + i, n)))
+        pcm_off += x.size
+        out_off += gpu.encoded_size(ch, n)
+    pcm = torch.from_numpy(np.concatenate(pcm_parts)).cuda()
+    out = torch.zeros(out_off, dtype=torch.uint8, device="cuda")
+    plan = batch.EncodePlan(clips, fl)
+    assert plan.samples == pcm.numel() and plan.out_bytes == out_off
+    plan.run(pcm, out)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    for (po, oo, d), x in zip(clips, pcm_parts):
+        want = oracle.encode_all(x, d.channels, d.sample_rate, d.samples)
+        assert host[oo:oo + len(want)].tobytes() == want, (d, flags)
+    # decode the batch back with the plan built from the descs, and with the plan built by walking the bytes
+    dplan = batch.DecodePlan.from_clips(clips)
+    back = torch.zeros_like(pcm)
+    dplan.run(out, back)
+    assert dplan.mismatches() == 0
+    streams = [host[oo:oo + gpu.encoded_size(d.channels, d.samples)].tobytes() for (_, oo, d) in clips]
+    splan = batch.DecodePlan.from_streams(streams, [oo for (_, oo, _) in clips], [po for (po, _, _) in clips])
+    assert splan.status == [0] * len(clips)
+    back2 = torch.zeros_like(pcm)
+    splan.run(out, back2)
+    torch.cuda.synchronize()
+    for (po, oo, d), s in zip(clips, streams):
+        _, _, want = oracle.decode_all(s)
+        assert np.array_equal(back[po:po + want.size].cpu().numpy(), want)
+        assert np.array_equal(back2[po:po + want.size].cpu().numpy(), want)
+
+
+def test_decoder_item_order_matches_reference_iterator(gpu, oracle):
+    """QoaItem sequence (FrameHeader, n*ch Samples, ..., None / Err) on well-formed, partial, truncated,
+    streaming-mode and channel-changing streams, item for item against the oracle's iterator."""
+    x2 = rng_pcm(1, 5200 * 2)
+    enc2 = oracle.encode_all(x2, 2, 32000, 5200)
+    x3 = rng_pcm(2, 130 * 3)
+    enc3 = oracle.encode_all(x3, 3, 8000, 130)
+    streaming = b"qoaf\0\0\0\0" + enc2[8:] + enc3[8:] + enc2[8:]      # channel count changes per frame
+    short_n = bytearray(enc3)
+    short_n[12:14] = (55).to_bytes(2, "big")                           # fewer samples than the slices present
+    cases = [enc2, enc3, enc2[:-5], enc2[: 8 + 4136 + 30], enc2[: 8 + 4136 + 8 + 32 + 16 * 3 + 7],
+             streaming, streaming[:-9], bytes(short_n), enc2 + enc3[8:]]
+    for data in cases:
+        ref = oracle.OracleDecoder(data)
+        dec = gpu.QoaDecoder(data)
+        m = dec.mode()
+        assert (("Streaming",) if isinstance(m, gpu.Streaming) else ("FixedSamples", m.channels, m.sample_rate, m.samples)) \
+            == ref.mode()
+        while True:
+            want = ref.next()
+            try:
+                got = dec.next()
+            except gpu.DecodeError as e:
+                got = ("Err", e.kind)
+            if want is None:
+                assert got is None
+                break
+            if want[0] == "Sample":
+                assert got == gpu.Sample(want[1])
+            elif want[0] == "FrameHeader":
+                assert got == gpu.FrameHeader(*want[1])
+                assert dec.current_frame_header() == got
+            else:
+                assert got == want
+                break
+
+
+def test_streaming_decoder_decode_frame(gpu, oracle, fixture_bytes):
+    """src/lib.rs:1034-1066, plus sample values and a multi-frame append."""
+    dec = gpu.QoaDecoder.new_streaming()
+    ref = oracle.OracleDecoder(streaming=True)
+    assert isinstance(dec.mode(), gpu.Streaming)
+    pos = 8
+    for _ in range(3):
+        fs = int.from_bytes(fixture_bytes[pos + 6:pos + 8], "big")
+        got = dec.decode_frame(fixture_bytes[pos:pos + fs])
+        want = ref.decode_frame(fixture_bytes[pos:pos + fs])
+        assert got.size == 5120 * 2 and np.array_equal(got, want)
+        pos += fs
+    two = fixture_bytes[pos:pos + 2 * 4136]
+    assert np.array_equal(dec.decode_frame(two), ref.decode_frame(two))
+    with pytest.raises(gpu.DecodeError) as e:
+        dec.decode_frame(fixture_bytes[pos:pos + 100])  # truncated frame
+    assert e.value.kind == "IoError"
+
+
+def test_decode_plan_status_for_bad_streams(gpu, oracle):
+    from qoaudio_amd import batch
+    x = rng_pcm(3, 700 * 2)
+    good = oracle.encode_all(x, 2, 44100, 700)
+    streams = [good, good[:-3], b"riff" + good[4:], good[:8], b"qoaf\0\0\0\1" + bytes(8)]
+    offs_in, offs_out, a, b = [], [], 0, 0
+    for s in streams:
+        offs_in.append(a)
+        offs_out.append(b)
+        a += (len(s) + 7) // 8 * 8
+        b += 1400
+    plan = batch.DecodePlan.from_streams(streams, offs_in, offs_out)
+    assert plan.status == [0, 5, 1, 2, 3]
+    assert plan.samples_out == [1400, 680 * 2, 0, 0, 0]
+    buf = np.zeros(a, np.uint8)
+    for s, o in zip(streams, offs_in):
+        buf[o:o + len(s)] = np.frombuffer(s, np.uint8)
+    out = torch.zeros(b, dtype=torch.int16, device="cuda")
+    plan.run(torch.from_numpy(buf).cuda(), out)
+    torch.cuda.synchronize()
+    _, _, want = oracle.decode_all(good)
+    host = out.cpu().numpy()
+    assert np.array_equal(host[:1400], want)
+    assert np.array_equal(host[1400:1400 + 1360], want[:1360])
+
+
+def test_decode_plan_detects_header_mismatch(gpu, oracle):
+    from qoaudio_amd import batch
+    x = rng_pcm(4, 6000 * 2)
+    desc = gpu.QoaDesc(2, 44100, 6000)
+    enc = np.frombuffer(oracle.encode_all(x, 2, 44100, 6000), np.uint8).copy()
+    clips, _, per_enc = batch.uniform_clips(1, desc)
+    enc[8 + 1] ^= 0x40  # corrupt the sample rate of frame 0
+    plan = batch.DecodePlan.from_clips(clips)
+    pcm = torch.zeros(12000, dtype=torch.int16, device="cuda")
+    plan.run(torch.from_numpy(enc).cuda(), pcm)
+    assert plan.mismatches() == 1
+    with pytest.raises(gpu.DecodeError):
+        batch.decode_batch(torch.from_numpy(enc).cuda().reshape(1, -1), desc)
+
+
+def test_full_size_batch_properties(gpu, oracle):
+    """BASELINE config 3 at FULL size (1024 stereo clips x 256 frames = 2.68 G samples, 5.4 GB of PCM in HBM),
+    through size-independent properties: (1) every copy of a clip encodes to identical bytes (checksum of
+    checksums over 1024 clips), (2) the distinct clips equal the oracle byte for byte, (3) decode(encode(x))
+    equals the oracle's decode of the same bytes and every header verifies."""
+    from qoaudio_amd import batch, synth
+    n_clips, distinct, frames, ch = 1024, 8, 256, 2
+    samples = frames * 5120
+    base = synth.make_clips(distinct, samples, ch, device="cuda")
+    pcm = base.repeat((n_clips // distinct, 1, 1)).contiguous()
+    desc = gpu.QoaDesc(ch, 44100, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
+    assert per_enc == 1058824
+    plan = batch.EncodePlan(clips)
+    assert (plan.pcm_bytes, plan.out_bytes, plan.samples) == (5368709120, 1084235776, 2684354560)
+    out = torch.empty((n_clips, per_enc), dtype=torch.uint8, device="cuda")
+    plan.run(pcm, out)
+    torch.cuda.synchronize()
+    ref_block = out[:distinct]
+    for rep in range(n_clips // distinct):
+        assert torch.equal(out[rep * distinct:(rep + 1) * distinct], ref_block)
+    host_pcm = base[:2].cpu().numpy()
+    host_enc = out[:2].cpu().numpy()
+    for i in range(2):
+        assert host_enc[i].tobytes() == oracle.encode_all(host_pcm[i].reshape(-1), ch, 44100, samples)
+    dplan = batch.DecodePlan.from_clips(clips)
+    back = torch.empty_like(pcm)
+    dplan.run(out, back)
+    assert dplan.mismatches() == 0
+    for rep in (0, n_clips // distinct - 1):
+        assert torch.equal(back[rep * distinct:(rep + 1) * distinct], back[:distinct])
+    _, _, want = oracle.decode_all(host_enc[1].tobytes())
+    assert np.array_equal(back[1].cpu().numpy().reshape(-1), want)
+    err = (back[:distinct].to(torch.float32) - base.to(torch.float32))
+    assert float(err.pow(2).mean().sqrt()) < 500.0  # the reference's round-trip bound, src/lib.rs:1258
+
+
+def test_mono_config2_slice(gpu, oracle):
+    """BASELINE config 2 shape (mono, 1024 clips) at 4 frames per clip, every clip distinct."""
+    from qoaudio_amd import batch, synth
+    n_clips, samples = 1024, 4 * 5120
+    pcm = synth.make_clips(n_clips, samples, 1, device="cuda", kind="white")
+    enc = batch.encode_batch(pcm, 44100)
+    torch.cuda.synchronize()
+    hp, he = pcm.cpu().numpy(), enc.cpu().numpy()
+    for i in (0, 1, 511, 1023):
+        assert he[i].tobytes() == oracle.encode_all(hp[i].reshape(-1), 1, 44100, samples)
+    back = batch.decode_batch(enc, gpu.QoaDesc(1, 44100, samples))
+    _, _, want = oracle.decode_all(he[1023].tobytes())
+    assert np.array_equal(back[1023].cpu().numpy().reshape(-1), want)

@@ -1,0 +1,117 @@
+"""The reference crate's own tests (src/lib.rs:991-1298, fuzz targets, bench assertion), through the
+Python mirror of its API and -- compiled from tests/cpp/reference_suite.cpp -- through the C++ mirror."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURE, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_iterating_through_whole_file(gpu, fixture_bytes):  # src/lib.rs:998-1032
+    qoa = gpu.QoaDecoder(fixture_bytes)
+    assert qoa.mode() == gpu.FixedSamples(2, 44100, 2394122)
+    assert abs(qoa.total_duration() - 2394122 / 44100) < 1e-9
+    headers = samples = 0
+    while True:
+        item = qoa.next()
+        if item is None:
+            break
+        if isinstance(item, gpu.Sample):
+            samples += 1 + qoa.read_samples(1 << 20).size  # bulk drain to the next header
+        else:
+            assert item.num_channels == 2 and item.sample_rate == 44100
+            headers += 1
+            assert item.num_samples_per_channel == (5120 if headers < 468 else 3082)
+    assert (headers, samples) == (468, 2394122 * 2)
+
+
+def test_bench_item_count_via_plain_iteration(gpu, fixture_bytes):  # benches/qoa_benchmarks.rs:8-12
+    data = fixture_bytes[: 8 + 3 * 4136]  # three frames, item by item through the FFI
+    assert sum(1 for _ in gpu.QoaDecoder(data)) == 3 * 5120 * 2 + 3
+
+
+def test_decode_all(gpu, fixture_bytes):  # src/lib.rs:1068-1074
+    d = gpu.decode_all(fixture_bytes)
+    assert (d.sample_rate, d.num_channels, d.samples.size) == (44100, 2, 2394122 * 2)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_encode_decode_sine(gpu, channels):  # src/lib.rs:1076-1146
+    sr = 44100
+    n = int(sr * 0.1)
+    t = np.arange(n) / sr
+    cols = [np.sin(t * 440.0 * 2.0 * np.pi) * 16384.0, np.cos(t * 440.0 * 2.0 * np.pi) * 16384.0][:channels]
+    samples = np.stack(cols, axis=1).astype(np.int16).reshape(-1)  # `as i16` truncates toward zero
+    encoded = gpu.encode_all(samples, gpu.QoaDesc(channels, sr, n))
+    assert len(encoded) > gpu.QOA_HEADER_SIZE
+    d = gpu.decode_all(encoded)
+    assert (d.sample_rate, d.num_channels, d.samples.size) == (sr, channels, samples.size)
+
+
+def test_encoder_errors(gpu):  # src/lib.rs:1148-1183
+    z = np.zeros(1000, np.int16)
+    for desc, kind in ((gpu.QoaDesc(0, 44100, 1000), "InvalidChannels"), (gpu.QoaDesc(1, 0, 1000), "InvalidSampleRate"),
+                       (gpu.QoaDesc(1, 44100, 0), "InvalidSamples")):
+        with pytest.raises(gpu.EncodeError) as e:
+            gpu.encode_all(z, desc)
+        assert e.value.kind == kind
+
+
+def test_round_trip_audio(gpu):  # src/lib.rs:1185-1230
+    samples = np.array([((i % 200) - 100) * 100 for i in range(1000)], dtype=np.int16)
+    encoded = gpu.encode_all(samples, gpu.QoaDesc(1, 44100, 1000))
+    d = gpu.decode_all(encoded)
+    assert (d.sample_rate, d.num_channels, d.samples.size) == (44100, 1, 1000)
+    assert int(np.abs(samples.astype(int) - d.samples.astype(int)).max()) < 8000
+
+
+def test_full_file_round_trip(gpu, fixture_bytes):  # src/lib.rs:1232-1259
+    original = gpu.decode_all(fixture_bytes)
+    desc = gpu.QoaDesc(original.num_channels, original.sample_rate, original.samples.size // original.num_channels)
+    decoded = gpu.decode_all(gpu.encode_all(original.samples, desc))
+    assert (decoded.num_channels, decoded.sample_rate, decoded.samples.size) == (2, 44100, original.samples.size)
+    rms = float(np.sqrt(np.mean((original.samples.astype(np.float64) - decoded.samples.astype(np.float64)) ** 2)))
+    assert rms < 500.0
+
+
+def test_fuzz_encode_round_trip_invariants(gpu):  # fuzz/fuzz_targets/encode_round_trip.rs
+    r = np.random.default_rng(2024)
+    for _ in range(40):
+        data = r.integers(0, 256, int(r.integers(4, 4000)), dtype=np.uint8).tobytes()
+        channels = data[0] % 8 + 1
+        num_i16 = (len(data) - 1) // 2
+        if num_i16 < channels:
+            continue
+        spc = num_i16 // channels
+        samples = np.frombuffer(data[1:1 + spc * channels * 2], dtype="<i2")
+        d = gpu.decode_all(gpu.encode_all(samples, gpu.QoaDesc(channels, 44100, spc)))
+        assert (d.num_channels, d.sample_rate, d.samples.size) == (channels, 44100, samples.size)
+
+
+def test_fuzz_iter_all_never_crashes(gpu, oracle):  # fuzz/fuzz_targets/iter_all.rs
+    r = np.random.default_rng(77)
+    good = oracle.encode_all(r.integers(-9000, 9000, 600 * 2).astype(np.int16), 2, 44100, 600)
+    for i in range(60):
+        b = bytearray(good if i % 2 else b"qoaf" + r.integers(0, 256, 200, dtype=np.uint8).tobytes())
+        for _ in range(3):
+            b[int(r.integers(0, min(len(b), 80)))] = int(r.integers(0, 256))
+        try:
+            n = sum(1 for _ in gpu.QoaDecoder(bytes(b)))
+            assert n >= 0
+        except gpu.DecodeError:
+            pass
+
+
+def test_cpp_mirror_runs_the_reference_suite(gpu, tmp_path):
+    exe = tmp_path / "reference_suite"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "reference_suite.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "qoaudio_amd"), "-lqoaudio_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "qoaudio_amd")])
+    r = subprocess.run([str(exe), FIXTURE], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("ok   test_") == 10

@@ -1,0 +1,222 @@
+"""The CPU oracle against every golden vector there is for this path.
+
+KAT-1 is the one with independent evidence: the reference's fixture was produced by a different
+encoder, and encode(decode(fixture)) reproduces it byte-for-byte through 259 complete frames.
+KAT-2..6 were recorded by the survey from an independent Python restatement of src/lib.rs; the C
+oracle reproducing them means two restatements agree.  The remaining tests are the reference's own
+tests (src/lib.rs:991-1298) run against the oracle.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import rng_pcm
+
+KAT1_PREFIX = 1_073_768
+FIXTURE_SHA256 = "b8d822ffee42abe052dfaab00136e86c3c1e9eb6e86cd700867b61a9f45a3372"
+KAT3_PCM_SHA256 = "2ed7d9a42d13659a6ff51b04728499d99ac99686326b87f215fdeabe05522619"
+KAT4_HEX = ("716f61660000002d0100ac44002d0030000000000000000000000000e000400000d10d0200051451045145145145145104"
+            "51400000000000")
+KAT5_SHA256 = "b05c7a346d8e34a1b0a26e0d648d525b7e56e3543559eadd86b9605e24924e9f"
+KAT6_HEX = ("716f6166000000320200bb8000320058000000000000000000000000e0004000000000000000000000000000e0004000"
+            "fb034c020fc0b4d1fdfacbeaf37757b8f03e6090515e0241fdd7dc2a1348afaae080f98200000000f0d213e600000000")
+KAT2_TOTALS = [522117267, 525200405, 119383785, 43336318, 1587308, 1582747, 1887874, 1946592, 2513046, 3221590,
+               4272064, 3964616, 6487859, 13440220, 24107150, 16356911]
+
+
+def test_fixture_identity(fixture_bytes):
+    assert len(fixture_bytes) == 1_934_040
+    assert hashlib.sha256(fixture_bytes).hexdigest() == FIXTURE_SHA256
+
+
+def test_kat3_decoded_fixture_pcm(fixture_pcm):
+    assert hashlib.sha256(fixture_pcm.astype("<i2").tobytes()).hexdigest() == KAT3_PCM_SHA256
+    assert (int(fixture_pcm.min()), int(fixture_pcm.max())) == (-31688, 29695)
+
+
+@pytest.mark.parametrize("search", [0, 1], ids=["ref_style", "exhaustive"])
+def test_kat1_fixture_fixed_point(oracle, fixture_bytes, fixture_pcm, search):
+    enc = oracle.encode_all(fixture_pcm, 2, 44100, fixture_pcm.size // 2, search)
+    assert len(enc) == len(fixture_bytes)
+    assert enc[:KAT1_PREFIX] == fixture_bytes[:KAT1_PREFIX]
+    a = np.frombuffer(enc, np.uint8)
+    b = np.frombuffer(fixture_bytes, np.uint8)
+    assert int(np.nonzero(a != b)[0][0]) == KAT1_PREFIX  # frame 259, slice row 156, channel 0
+
+
+def test_kat2_slice_search(oracle):
+    s, sf, (hist, weights), totals = oracle.encode_slice(
+        [-2655, -1631, -965, -806], [-5363, 11763, -15085, 16783],
+        [-857, -665, -532, -205, 97, 453, 1182, 2249, 3636, 4729, 5942, 7621, 8992, 9889, 10639, 11477, 12145, 12013,
+         11809, 11685])
+    assert (hex(s), sf) == ("0x56484f1ce06cd14a", 5)
+    assert totals == KAT2_TOTALS
+    s2, sf2, _, _ = oracle.encode_slice([-2655, -1631, -965, -806], [-5363, 11763, -15085, 16783],
+                                        [-857, -665, -532, -205, 97, 453, 1182, 2249, 3636, 4729, 5942, 7621, 8992,
+                                         9889, 10639, 11477, 12145, 12013, 11809, 11685], search=oracle.REF_STYLE)
+    assert (s2, sf2) == (s, sf)
+
+
+def test_kat4_silence_with_tail(oracle):
+    assert oracle.encode_all(np.zeros(45, np.int16), 1, 44100, 45).hex() == KAT4_HEX
+
+
+def test_kat5_sawtooth(oracle):
+    saw = np.array([((i % 200) - 100) * 100 for i in range(1000)], dtype=np.int16)
+    e = oracle.encode_all(saw, 1, 44100, 1000)
+    assert len(e) == 432 and hashlib.sha256(e).hexdigest() == KAT5_SHA256
+    _, _, d = oracle.decode_all(e)
+    assert int(np.abs(saw.astype(int) - d.astype(int)).max()) == 5665  # reference asserts < 8000, src/lib.rs:1225
+
+
+def test_kat6_stereo_48k(oracle):
+    L = [((i * 37) % 400 - 200) * 50 for i in range(50)]
+    R = [-(((i * 91) % 300) - 150) * 80 for i in range(50)]
+    st = np.array([v for p in zip(L, R) for v in p], dtype=np.int16)
+    assert oracle.encode_all(st, 2, 48000, 50).hex() == KAT6_HEX
+
+
+# ---- the reference's own tests, against the oracle ----
+
+def test_iterating_through_whole_file(oracle, fixture_bytes):  # src/lib.rs:998-1032
+    dec = oracle.OracleDecoder(fixture_bytes)
+    assert dec.mode() == ("FixedSamples", 2, 44100, 2394122)
+    headers, samples = 0, 0
+    for kind, val in dec:
+        if kind == "Sample":
+            samples += 1
+        else:
+            assert kind == "FrameHeader" and val[0] == 2 and val[1] == 44100
+            headers += 1
+            assert val[2] == (5120 if headers < 468 else 3082)
+    assert (headers, samples) == (468, 2394122 * 2)
+
+
+def test_decode_streaming_frames(oracle, fixture_bytes):  # src/lib.rs:1034-1066
+    dec = oracle.OracleDecoder(streaming=True)
+    assert dec.mode() == ("Streaming",)
+    fs = int.from_bytes(fixture_bytes[14:16], "big")
+    end1 = 8 + fs
+    assert dec.decode_frame(fixture_bytes[8:end1]).size == 5120 * 2
+    fs2 = int.from_bytes(fixture_bytes[end1 + 6:end1 + 8], "big")
+    assert dec.decode_frame(fixture_bytes[end1:end1 + fs2]).size == 5120 * 2
+
+
+def test_encoder_errors(oracle):  # src/lib.rs:1148-1183
+    z = np.zeros(1000, np.int16)
+    for desc, kind in (((0, 44100, 1000), "InvalidChannels"), ((9, 44100, 1000), "InvalidChannels"),
+                       ((1, 0, 1000), "InvalidSampleRate"), ((1, 44100, 0), "InvalidSamples"),
+                       ((0, 0, 0), "InvalidChannels"), ((1, 0, 0), "InvalidSampleRate")):
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.encode_all(z, *desc)
+        assert e.value.kind == kind
+    with pytest.raises(oracle.OracleError) as e:  # length mismatch, :368-370
+        oracle.encode_all(z, 1, 44100, 999)
+    assert e.value.kind == "InvalidSamples"
+
+
+def test_full_file_round_trip_and_streaming_encode(oracle, fixture_pcm):  # src/lib.rs:1232-1297
+    n = fixture_pcm.size // 2
+    oneshot = oracle.encode_all(fixture_pcm, 2, 44100, n)
+    _, _, dec = oracle.decode_all(oneshot)
+    assert dec.size == fixture_pcm.size
+    rms = float(np.sqrt(np.mean((fixture_pcm.astype(np.float64) - dec.astype(np.float64)) ** 2)))
+    assert rms < 500.0
+    enc = oracle.OracleEncoder(2, 44100, n)
+    streamed = bytearray(enc.write_header())
+    off = 0
+    while off < n:
+        fl = min(5120, n - off)
+        data, got = enc.encode_frame(fixture_pcm[off * 2:(off + fl) * 2])
+        assert got == fl
+        streamed += data
+        off += fl
+    assert bytes(streamed) == oneshot
+    for bad in (np.zeros(0, np.int16), np.zeros(3, np.int16), np.zeros(5121 * 2, np.int16)):  # :424-430
+        with pytest.raises(oracle.OracleError) as e:
+            enc.encode_frame(bad)
+        assert e.value.kind == "InvalidSamples"
+
+
+@pytest.mark.parametrize("channels", range(1, 9))
+def test_two_search_forms_agree(oracle, channels):
+    """ref_style (rank-sorted order + early exits) == exhaustive argmin(total, first, sf), byte for byte."""
+    for kind in ("mix", "white", "loud", "silence", "square"):
+        for n in (1, 19, 20, 21, 45, 700, 5121):
+            x = rng_pcm(channels * 1000 + n, n * channels, kind)
+            a = oracle.encode_all(x, channels, 44100, n, oracle.REF_STYLE)
+            b = oracle.encode_all(x, channels, 44100, n, oracle.EXHAUSTIVE)
+            assert a == b, (kind, n)
+            assert len(a) == oracle.encoded_size(channels, n)
+            ch, sr, d = oracle.decode_all(a)  # fuzz/encode_round_trip.rs invariants
+            assert (ch, sr, d.size) == (channels, 44100, x.size)
+
+
+def test_rank_ties_pick_first_in_sorted_order(oracle):
+    """Digital silence makes many candidates tie on total rank: the winner must be the first in
+    (first-sample rank, sf) order (strict '<' at src/lib.rs:587, stable sort at :536)."""
+    for n in (20, 40, 400):
+        x = np.zeros(n, np.int16)
+        assert oracle.encode_all(x, 1, 8000, n, 0) == oracle.encode_all(x, 1, 8000, n, 1)
+
+
+def test_candidate_steps_instrumentation(oracle, fixture_pcm):
+    """The survey's probe: ~41.3 of 320 candidate-steps per slice on the reference's own bench input."""
+    n = 5120 * 40
+    e = oracle.OracleEncoder(2, 44100, n)
+    e.encode(fixture_pcm[: n * 2])
+    per_slice = e.candidate_steps / e.slices
+    assert 16 <= per_slice < 320
+    x = oracle.OracleEncoder(2, 44100, n, oracle.EXHAUSTIVE)
+    x.encode(fixture_pcm[: n * 2])
+    assert x.candidate_steps / x.slices == 320
+
+
+def test_decoder_item_order_partial_and_truncated(oracle):
+    x = rng_pcm(5, 45 * 2)
+    enc = oracle.encode_all(x, 2, 22050, 45)
+    items = list(oracle.OracleDecoder(enc))
+    assert items[0] == ("FrameHeader", (2, 22050, 45))
+    assert [k for k, _ in items[1:]] == ["Sample"] * 90
+    # cut inside the last slice row: the rows before it are yielded, then IoError
+    cut = enc[:-4]
+    items = list(oracle.OracleDecoder(cut))
+    assert items[-1] == ("Err", "IoError")
+    assert sum(1 for k, _ in items if k == "Sample") == 40 * 2
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.decode_all(cut)
+    assert e.value.kind == "IoError"
+    for data, kind in ((b"", "IoError"), (b"qoa", "IoError"), (b"riff0000", "NotQoaFile"), (b"qoaf\0\0\0\1", "NoSamples"),
+                       (b"qoaf\0\0\0\1" + bytes(8), "InvalidFrameHeader")):
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.OracleDecoder(data)
+        assert e.value.kind == kind
+
+
+def test_sanitized_build_runs_clean(oracle, fixture_pcm):
+    """UBSan/ASan build of the oracle (wrapping arithmetic is done in uint32_t on purpose)."""
+    import ctypes as C
+    import subprocess, sys, os
+    path = oracle.build(san=True)
+    code = (
+        "import ctypes as C, numpy as np, sys\n"
+        f"L = C.CDLL({path!r})\n"
+        "L.oq_encoded_size.restype = C.c_size_t\n"
+        "x = (np.random.default_rng(1).integers(-32768, 32768, 6000*3)).astype(np.int16)\n"
+        "x[::7] = 32767; x[1::7] = -32768\n"
+        "class D(C.Structure): _fields_=[('c',C.c_uint8),('r',C.c_uint32),('s',C.c_uint32)]\n"
+        "d = D(3, 44100, 6000); out = np.zeros(L.oq_encoded_size(3, 6000), np.uint8); w = C.c_size_t(0)\n"
+        "for mode in (0, 1):\n"
+        "    rc = L.oq_encode_all(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.size), C.byref(d), mode, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(w))\n"
+        "    assert rc == 0\n"
+        "n = C.c_size_t(0); ch = C.c_uint8(0); sr = C.c_uint32(0); pcm = np.zeros(x.size, np.int16)\n"
+        "rc = L.oq_decode_all(out.ctypes.data_as(C.c_void_p), C.c_size_t(w.value), C.byref(ch), C.byref(sr), pcm.ctypes.data_as(C.c_void_p), C.c_size_t(pcm.size), C.byref(n))\n"
+        "assert rc == 0 and n.value == x.size\n"
+        "print('clean')\n")
+    env = dict(os.environ)
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env["LD_PRELOAD"] = asan
+    env["ASAN_OPTIONS"] = "detect_leaks=0"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
