@@ -100,6 +100,13 @@ int qoa_encoder_encode_frame(qoa_encoder *enc, const int16_t *pcm, size_t n_i16,
 int qoa_encoder_get_lms(qoa_encoder *enc, int32_t *state /* channels*8 */);
 int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state /* channels*8 */);
 
+/* Test hook: run ONE slice (src/lib.rs:495-596) from an explicit entry state through the device functions of
+ * the encode kernel and return all 16 candidates: total rank, first-sample rank, packed slice (tail already
+ * left-aligned) and end LMS state [16][8].  generic != 0 forces the 32-bit-multiply path. */
+int qoa_debug_encode_slice(const int32_t *state /* 8 */, const int16_t *samples, int len /* 1..20 */, int generic,
+                           uint64_t *total_rank /* 16 */, uint64_t *first_rank /* 16 */, uint64_t *slices /* 16 */,
+                           int32_t *end_states /* 16*8 */);
+
 /* encode_all, src/lib.rs:760-763. */
 int qoa_encode_all(const int16_t *pcm, size_t n_i16, const qoa_desc *desc, uint8_t *out, size_t cap,
                    size_t *written);

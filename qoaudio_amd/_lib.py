@@ -16,7 +16,7 @@ SYMBOLS = [
     "qoa_encode_strerror", "qoa_decode_strerror", "qoa_last_error_detail", "qoa_version",
     "qoa_encoded_size", "qoa_frame_size",
     "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
-    "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_encode_all",
+    "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_encode_all",
     "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run",
     "qoa_decoder_new", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
     "qoa_decoder_current_frame_header", "qoa_decoder_total_duration", "qoa_decoder_next",
@@ -66,6 +66,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; load it first so that this process has ONE HIP runtime (a second
+    # copy loaded from /opt/rocm finds "no ROCm-capable device").  torch is plumbing only.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -91,6 +97,7 @@ def lib():
     L.qoa_encoder_encode_frame.argtypes = [vp, vp, sz, vp, sz, szp, szp]
     L.qoa_encoder_get_lms.argtypes = [vp, vp]
     L.qoa_encoder_set_lms.argtypes = [vp, vp]
+    L.qoa_debug_encode_slice.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.qoa_encode_all.argtypes = [vp, sz, C.POINTER(Desc), vp, sz, szp]
     L.qoa_encode_plan_create.argtypes = [C.POINTER(Clip), sz, C.c_uint32, C.POINTER(vp)]
     L.qoa_encode_plan_free.argtypes = [vp]

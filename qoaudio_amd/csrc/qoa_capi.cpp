@@ -337,6 +337,31 @@ extern "C" int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state) {
     return QOA_OK;
 }
 
+// Test hook: the 16 candidates of ONE slice through the device functions of the encode kernel.
+extern "C" int qoa_debug_encode_slice(const int32_t *state, const int16_t *samples, int len, int generic,
+                                      uint64_t *total_rank, uint64_t *first_rank, uint64_t *slices,
+                                      int32_t *end_states) {
+    if (!state || !samples || len < 1 || len > 20) return fail_msg("bad argument", QOA_ENCODE_IO_ERROR);
+    int32_t smp[20] = {0};
+    for (int i = 0; i < len; i++) smp[i] = samples[i];
+    DevBuf d;
+    const size_t o_state = 0, o_smp = 64, o_tot = 256, o_fst = 512, o_slice = 768, o_end = 1024, total = 1024 + 512;
+    HIP_TRY(d.reserve(total), QOA_ENCODE_IO_ERROR);
+    char *b = (char *)d.p;
+    HIP_TRY(hipMemcpy(b + o_state, state, 32, hipMemcpyHostToDevice), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(b + o_smp, smp, 80, hipMemcpyHostToDevice), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(launch_debug_slice((const int32_t *)(b + o_state), (const int32_t *)(b + o_smp), len, generic,
+                               (unsigned long long *)(b + o_tot), (unsigned long long *)(b + o_fst),
+                               (unsigned long long *)(b + o_slice), (int32_t *)(b + o_end), nullptr),
+            QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR);
+    if (total_rank) HIP_TRY(hipMemcpy(total_rank, b + o_tot, 128, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    if (first_rank) HIP_TRY(hipMemcpy(first_rank, b + o_fst, 128, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    if (slices) HIP_TRY(hipMemcpy(slices, b + o_slice, 128, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    if (end_states) HIP_TRY(hipMemcpy(end_states, b + o_end, 512, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    return QOA_OK;
+}
+
 extern "C" int qoa_encode_all(const int16_t *pcm, size_t n_i16, const qoa_desc *desc, uint8_t *out, size_t cap,
                               size_t *written) { // src/lib.rs:760-763
     qoa_encoder *e = nullptr;

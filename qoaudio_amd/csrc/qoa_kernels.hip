@@ -39,7 +39,20 @@ __constant__ int c_mags[16][4] = QOA_DEQUANT_MAGS;
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// 24-bit multiplies as single instructions with EXACT wrapping semantics: the low 32 bits of
+// sext24(a) * sext24(b) (+ c).  Not HIP's __mul24: that is `mul nsw` in the device library, i.e. signed
+// overflow is undefined, and hipcc then narrows a u64 rank sum to 32 bits (caught by the parity tests:
+// err^2 reaches 2^32).  Inline asm keeps the instruction and drops the assumption.
+__device__ __forceinline__ int mul24(int a, int b) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int mul32(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 // clamp(v, lo, hi); the backend folds min(max()) with constant bounds into one v_med3_i32
 __device__ __forceinline__ int med3(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -85,17 +98,25 @@ struct CandResult {
 template <bool FAST>
 __device__ __forceinline__ void cand_step(int smp, int recip, unsigned dq_lo, unsigned dq_hi, Lms &l, int &s0,
                                           int &s1, int &s2, int &s3, unsigned &e2, unsigned &p2, int &code) {
-    auto MUL = [](int a, int b) { return FAST ? mul24(a, b) : mul32(a, b); };
     // predict: ((w0h0 + w1h1) + (w2h2 + w3h3)) >> 13, wrapping   (src/lib.rs:811-813)
-    int p = wadd(wadd(MUL(l.w0, l.h0), MUL(l.w1, l.h1)), wadd(MUL(l.w2, l.h2), MUL(l.w3, l.h3)));
-    int pred = p >> 13;
-    // weights penalty (src/lib.rs:814-817)
-    int q = wadd(wadd(MUL(l.w0, l.w0), MUL(l.w1, l.w1)), wadd(MUL(l.w2, l.w2), MUL(l.w3, l.w3)));
+    // weights penalty: max(0, ((w0w0 + w1w1 + w2w2 + w3w3) >> 18) - 0x8ff)   (src/lib.rs:814-817)
+    // qoa_div: ((res * recip + 2^15) >> 16) + sgn(res) - sgn(n)            (src/lib.rs:613-617)
+    int p, q, res, n, pred;
+    if (FAST) {
+        p = mad24(l.w3, l.h3, mad24(l.w2, l.h2, mad24(l.w1, l.h1, mul24(l.w0, l.h0))));
+        q = mad24(l.w3, l.w3, mad24(l.w2, l.w2, mad24(l.w1, l.w1, mul24(l.w0, l.w0))));
+        pred = p >> 13;
+        res = smp - pred;
+        n = mad24(res, recip, 1 << 15) >> 16;
+    } else {
+        p = wadd(wadd(mul32(l.w0, l.h0), mul32(l.w1, l.h1)), wadd(mul32(l.w2, l.h2), mul32(l.w3, l.h3)));
+        q = wadd(wadd(mul32(l.w0, l.w0), mul32(l.w1, l.w1)), wadd(mul32(l.w2, l.w2), mul32(l.w3, l.w3)));
+        pred = p >> 13;
+        res = smp - pred;
+        n = wadd(mul32(res, recip), 1 << 15) >> 16;
+    }
     int pen = max((q >> 18) - 0x8ff, 0);
-    p2 = (unsigned)mul24(pen, pen);
-    // qoa_div (src/lib.rs:613-617)
-    int res = smp - pred;
-    int n = wadd(MUL(res, recip), 1 << 15) >> 16;
+    p2 = (unsigned)mul24(pen, pen); // pen <= 5888
     int scaled = n + sgn(res) - sgn(n);
     // quantise + dequantise
     int sneg = scaled >> 31;
@@ -110,10 +131,10 @@ __device__ __forceinline__ void cand_step(int smp, int recip, unsigned dq_lo, un
     e2 = (unsigned)mul24(err, err); // |err| <= 65535: exact in 32 bits
     // LMS update (src/lib.rs:821-828): w_i += sign(h_i) * (deq >> 4); s_i = +-1 travels with h_i
     int delta = deq >> 4;
-    l.w0 = wadd(l.w0, mul24(s0, delta)); // |delta| <= 896, s = +-1: always 24-bit safe
-    l.w1 = wadd(l.w1, mul24(s1, delta));
-    l.w2 = wadd(l.w2, mul24(s2, delta));
-    l.w3 = wadd(l.w3, mul24(s3, delta));
+    l.w0 = mad24(s0, delta, l.w0); // |delta| <= 896, s = +-1: always 24-bit safe; the add wraps
+    l.w1 = mad24(s1, delta, l.w1);
+    l.w2 = mad24(s2, delta, l.w2);
+    l.w3 = mad24(s3, delta, l.w3);
     l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
     s0 = s1; s1 = s2; s2 = s3; s3 = (recon >> 31) | 1;
 }
@@ -356,6 +377,37 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Test hook: one slice, all 16 candidates, through the very same device functions as K1.  Returns every
+// candidate's total rank, first-sample rank, packed slice and end state so that tests can compare the
+// search lane by lane with the oracle (tests/test_gpu_parity.py, KAT-2).
+// ------------------------------------------------------------------------------------------------
+__global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const int32_t *__restrict__ samples, int len,
+                                       int generic, unsigned long long *__restrict__ tot,
+                                       unsigned long long *__restrict__ fst, unsigned long long *__restrict__ slice,
+                                       int32_t *__restrict__ end_state) {
+    const int sf = (int)(threadIdx.x & 15u);
+    if (threadIdx.x >= 16) return;
+    const int recip = c_recip[sf];
+    const unsigned dq_lo = (unsigned)c_mags[sf][0] | ((unsigned)c_mags[sf][1] << 16);
+    const unsigned dq_hi = (unsigned)c_mags[sf][2] | ((unsigned)c_mags[sf][3] << 16);
+    Lms st;
+    st.h0 = state[0]; st.h1 = state[1]; st.h2 = state[2]; st.h3 = state[3];
+    st.w0 = state[4]; st.w1 = state[5]; st.w2 = state[6]; st.w3 = state[7];
+    int smp[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) smp[i] = samples[i];
+    CandResult r;
+    if (generic || len != 20) run_slice_generic(smp, len, sf, recip, dq_lo, dq_hi, st, r);
+    else run_slice_fast(smp, sf, recip, dq_lo, dq_hi, st, r);
+    tot[sf] = (((unsigned long long)r.e_hi << 32) | r.e_lo) + r.pen;
+    fst[sf] = (unsigned long long)r.e0 + r.p0;
+    slice[sf] = ((unsigned long long)r.s_hi << 32) | r.s_lo;
+    int32_t *o = end_state + sf * 8;
+    o[0] = r.lms.h0; o[1] = r.lms.h1; o[2] = r.lms.h2; o[3] = r.lms.h3;
+    o[4] = r.lms.w0; o[5] = r.lms.w1; o[6] = r.lms.w2; o[7] = r.lms.w3;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: decode (v1: one lane per (frame, channel) chain, direct global loads/stores)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
@@ -410,8 +462,8 @@ __global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restri
             int recon = med3(pr + deq, -32768, 32767);
             rec[i] = (int16_t)recon;
             int delta = deq >> 4;
-            l.w0 = wadd(l.w0, mul24(s0, delta)); l.w1 = wadd(l.w1, mul24(s1, delta));
-            l.w2 = wadd(l.w2, mul24(s2, delta)); l.w3 = wadd(l.w3, mul24(s3, delta));
+            l.w0 = mad24(s0, delta, l.w0); l.w1 = mad24(s1, delta, l.w1);
+            l.w2 = mad24(s2, delta, l.w2); l.w3 = mad24(s3, delta, l.w3);
             l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
             s0 = s1; s1 = s2; s2 = s3; s3 = (recon >> 31) | 1;
         }
@@ -459,6 +511,14 @@ hipError_t launch_encode(int cpw, int nch, const int16_t *pcm, uint8_t *out, con
     case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, lds_bytes, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_debug_slice(const int32_t *state, const int32_t *samples, int len, int generic,
+                              unsigned long long *tot, unsigned long long *fst, unsigned long long *slice,
+                              int32_t *end_state, hipStream_t stream) {
+    hipLaunchKernelGGL(qoa_debug_slice_kernel, dim3(1), dim3(64), 0, stream, state, samples, len, generic, tot, fst,
+                       slice, end_state);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode(const uint8_t *in, int16_t *out, const DecChain *chains, unsigned n, unsigned *mismatches,

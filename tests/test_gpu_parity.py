@@ -319,3 +319,51 @@ def test_mono_config2_slice(gpu, oracle):
     back = batch.decode_batch(enc, gpu.QoaDesc(1, 44100, samples))
     _, _, want = oracle.decode_all(he[1023].tobytes())
     assert np.array_equal(back[1023].cpu().numpy().reshape(-1), want)
+
+
+def _gpu_slice(state, smp, generic=0):
+    import ctypes as C
+    from qoaudio_amd import _lib
+    st = np.asarray(state, np.int32)
+    s = np.asarray(smp, np.int16)
+    tot, fst, sl = np.zeros(16, np.uint64), np.zeros(16, np.uint64), np.zeros(16, np.uint64)
+    es = np.zeros((16, 8), np.int32)
+    rc = _lib.lib().qoa_debug_encode_slice(st.ctypes.data, s.ctypes.data, len(s), generic, tot.ctypes.data,
+                                           fst.ctypes.data, sl.ctypes.data, es.ctypes.data)
+    assert rc == 0
+    return [int(v) for v in tot], [int(v) for v in fst], [int(v) for v in sl], es
+
+
+def test_kat2_slice_search_lane_by_lane(gpu, oracle):
+    """KAT-2: all 16 candidates' total ranks of the fixture's first divergent slice, on the device."""
+    state = [-2655, -1631, -965, -806, -5363, 11763, -15085, 16783]
+    smp = [-857, -665, -532, -205, 97, 453, 1182, 2249, 3636, 4729, 5942, 7621, 8992, 9889, 10639, 11477, 12145,
+           12013, 11809, 11685]
+    want = [522117267, 525200405, 119383785, 43336318, 1587308, 1582747, 1887874, 1946592, 2513046, 3221590, 4272064,
+            3964616, 6487859, 13440220, 24107150, 16356911]
+    for generic in (0, 1):
+        tot, fst, sl, es = _gpu_slice(state, smp, generic)
+        assert tot == want
+        win = min((tot[i], fst[i], i) for i in range(16))[2]
+        assert (win, hex(sl[win])) == (5, "0x56484f1ce06cd14a")
+
+
+def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
+    """err^2 reaches 2^32 and the 64-bit rank sums carry on full-scale input; weights/history at extremes."""
+    r = np.random.default_rng(5)
+    for trial in range(60):
+        hist = [int(v) for v in r.integers(-32768, 32768, 4)]
+        scale = [20000, 40000, 2 ** 20, 2 ** 22][trial % 4]
+        w = [int(v) for v in r.integers(-scale, scale, 4)]
+        kind = ["white", "loud", "mix"][trial % 3]
+        length = 20 if trial % 5 else int(r.integers(1, 20))
+        smp = rng_pcm(trial, length, kind)
+        s, sf, (eh, ew), totals = oracle.encode_slice(hist, w, smp)
+        for generic in (0, 1):
+            tot, fst, sl, es = _gpu_slice(hist + w, smp, generic)
+            assert tot == totals, (trial, generic)
+            win = min((tot[i], fst[i], i) for i in range(16))[2]
+            assert win == sf
+            shift = (20 - length) * 3
+            assert sl[win] == (s << shift) & (2 ** 64 - 1)
+            assert list(es[win]) == eh + ew
