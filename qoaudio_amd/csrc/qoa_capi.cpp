@@ -423,24 +423,77 @@ int Walker::walk(const uint8_t *data, size_t len, size_t *pos_io, std::vector<Fr
     }
 }
 
-static void frames_to_chains(const std::vector<FrameRec> &frames, size_t first_frame, uint64_t in_base, uint64_t out_base,
-                             bool verify, std::vector<DecChain> &chains, uint64_t *samples_total) {
+// Device-side decode tables: frames of 1..8 channels go to K2 (one entry per frame, grouped by channel
+// count); frames with more channels (legal in the format, exotic in practice) go to the generic kernel with
+// one entry per (frame, channel) chain.
+struct DecTables {
+    DevBuf frames[kMaxChannels + 1];
+    unsigned n_frames[kMaxChannels + 1] = {0};
+    DevBuf chains;
+    unsigned n_chains = 0;
+    DevBuf mismatch;
+
+    hipError_t upload(const std::vector<DecChain> &recs, hipStream_t stream) {
+        std::vector<DecChain> per[kMaxChannels + 1], generic;
+        for (const DecChain &d : recs) {
+            if (d.rows == 0 || d.n_out == 0) continue;
+            if (d.channels <= kMaxChannels) per[d.channels].push_back(d);
+            else for (unsigned c = 0; c < d.channels; c++) {
+                DecChain e = d;
+                e.channel = (uint8_t)c;
+                e.out_off = d.out_off + c;
+                generic.push_back(e);
+            }
+        }
+        hipError_t e = mismatch.reserve(sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
+        for (int n = 1; n <= kMaxChannels && e == hipSuccess; n++) {
+            n_frames[n] = (unsigned)per[n].size();
+            if (per[n].empty()) continue;
+            e = frames[n].reserve(per[n].size() * sizeof(DecChain));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(frames[n].p, per[n].data(), per[n].size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
+        }
+        n_chains = (unsigned)generic.size();
+        if (e == hipSuccess && !generic.empty()) {
+            e = chains.reserve(generic.size() * sizeof(DecChain));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(chains.p, generic.data(), generic.size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream); // the host vectors above die with this call
+        return e;
+    }
+    bool empty() const {
+        if (n_chains) return false;
+        for (int n = 1; n <= kMaxChannels; n++) if (n_frames[n]) return false;
+        return true;
+    }
+    hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream) {
+        for (int n = 1; n <= kMaxChannels; n++) {
+            hipError_t e = launch_decode_frames(n, d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
+                                                (unsigned *)mismatch.p, stream);
+            if (e != hipSuccess) return e;
+        }
+        return launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, (unsigned *)mismatch.p, stream);
+    }
+};
+
+// One record per frame (the `channel` field is unused, out_off is the frame's first interleaved sample).
+static void frames_to_records(const std::vector<FrameRec> &frames, size_t first_frame, uint64_t in_base, uint64_t out_base,
+                              std::vector<DecChain> &recs, uint64_t *samples_total) {
     uint64_t out = out_base;
     for (size_t i = first_frame; i < frames.size(); i++) {
         const FrameRec &f = frames[i];
         if (f.rows > 0 && f.n_out > 0) {
-            for (unsigned c = 0; c < f.channels; c++) {
-                DecChain d;
-                d.frame_off = in_base + f.pos;
-                d.out_off = out + c;
-                d.n_out = f.n_out;
-                d.rows = (uint16_t)std::min<uint32_t>(f.rows, (f.n_out + kSliceLen - 1) / kSliceLen);
-                d.channels = f.channels;
-                d.channel = (uint8_t)c;
-                d.expect_hi = d.expect_lo = 0;
-                (void)verify;
-                chains.push_back(d);
-            }
+            DecChain d;
+            d.frame_off = in_base + f.pos;
+            d.out_off = out;
+            d.n_out = f.n_out;
+            d.rows = (uint16_t)std::min<uint32_t>(f.rows, (f.n_out + kSliceLen - 1) / kSliceLen);
+            d.channels = f.channels;
+            d.channel = 0;
+            d.expect_hi = d.expect_lo = 0;
+            recs.push_back(d);
         }
         out += (uint64_t)f.n_out * f.channels;
     }
@@ -480,19 +533,12 @@ extern "C" int qoa_stream_scan(const uint8_t *bytes, size_t len, qoa_stream_info
 // batch decode plan
 // ------------------------------------------------------------------------------------------------
 struct qoa_decode_plan {
-    DevBuf chains, mismatch;
-    unsigned n = 0;
+    DecTables t;
     uint64_t in_bytes = 0, pcm_bytes = 0, samples = 0;
 };
 
-static int plan_upload(qoa_decode_plan *plan, const std::vector<DecChain> &chains) {
-    plan->n = (unsigned)chains.size();
-    HIP_TRY(plan->chains.reserve(chains.size() * sizeof(DecChain)), QOA_DECODE_IO_ERROR);
-    HIP_TRY(plan->mismatch.reserve(sizeof(unsigned)), QOA_DECODE_IO_ERROR);
-    if (!chains.empty())
-        HIP_TRY(hipMemcpy(plan->chains.p, chains.data(), chains.size() * sizeof(DecChain), hipMemcpyHostToDevice),
-                QOA_DECODE_IO_ERROR);
-    HIP_TRY(hipMemset(plan->mismatch.p, 0, sizeof(unsigned)), QOA_DECODE_IO_ERROR);
+static int plan_upload(qoa_decode_plan *plan, const std::vector<DecChain> &recs) {
+    HIP_TRY(plan->t.upload(recs, nullptr), QOA_DECODE_IO_ERROR);
     return QOA_OK;
 }
 
@@ -521,7 +567,7 @@ extern "C" int qoa_decode_plan_from_streams(const uint8_t *const *streams, const
             std::vector<FrameRec> frames;
             st = w.walk(d, n, &pos, frames);
             if (w.mode == kFixed && frames.empty() && st == kTermEnd) st = QOA_DECODE_NO_SAMPLES;
-            frames_to_chains(frames, 0, in_offset[i], out_offset[i], false, chains, &n_i16);
+            frames_to_records(frames, 0, in_offset[i], out_offset[i], chains, &n_i16);
         }
         if (status) status[i] = st;
         if (samples_out) samples_out[i] = n_i16;
@@ -554,14 +600,14 @@ extern "C" int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips,
             uint32_t fl = std::min<uint32_t>(left, kFrameLen);
             uint32_t rows = (fl + kSliceLen - 1) / kSliceLen;
             uint32_t fsize = qoa_frame_size(d.channels, rows);
-            for (unsigned c = 0; c < d.channels; c++) {
+            {
                 DecChain dc;
                 dc.frame_off = pos;
-                dc.out_off = outp + c;
+                dc.out_off = outp;
                 dc.n_out = fl;
                 dc.rows = (uint16_t)rows;
                 dc.channels = d.channels;
-                dc.channel = (uint8_t)c;
+                dc.channel = 0;
                 dc.expect_hi = ((uint32_t)d.channels << 24) | d.sample_rate;
                 dc.expect_lo = (fl << 16) | fsize;
                 chains.push_back(dc);
@@ -597,15 +643,13 @@ extern "C" int qoa_decode_plan_bytes(const qoa_decode_plan *plan, uint64_t *in_b
 
 extern "C" int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_DECODE_IO_ERROR);
-    HIP_TRY(launch_decode(d_in, d_out, (const DecChain *)plan->chains.p, plan->n, (unsigned *)plan->mismatch.p,
-                          (hipStream_t)stream),
-            QOA_DECODE_IO_ERROR);
+    HIP_TRY(plan->t.run(d_in, d_out, (hipStream_t)stream), QOA_DECODE_IO_ERROR);
     return QOA_OK;
 }
 
 extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count) {
     if (!plan || !count) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
-    HIP_TRY(hipMemcpy(count, plan->mismatch.p, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(count, plan->t.mismatch.p, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
     return QOA_OK;
 }
 
@@ -628,15 +672,16 @@ struct qoa_decoder {
     bool finished_err = false;
     qoa_frame_header current{};    // CurrentFrame.header, :283-286
     hipStream_t stream = nullptr;
-    DevBuf d_in, d_out, d_chains, d_mismatch;
+    DevBuf d_in, d_out;
+    DecTables tables;
     ~qoa_decoder() { if (stream) (void)hipStreamDestroy(stream); }
 };
 
 // Decode frames [first_frame, end) on the GPU and append their PCM to dec->pcm.
 static int decoder_decode_new_frames(qoa_decoder *dec, size_t first_frame) {
-    std::vector<DecChain> chains;
+    std::vector<DecChain> recs;
     uint64_t n_i16 = 0;
-    frames_to_chains(dec->frames, first_frame, 0, 0, false, chains, &n_i16);
+    frames_to_records(dec->frames, first_frame, 0, 0, recs, &n_i16);
     size_t base = dec->pcm.size();
     {
         size_t off = base;
@@ -646,23 +691,17 @@ static int decoder_decode_new_frames(qoa_decoder *dec, size_t first_frame) {
         }
     }
     dec->pcm.resize(base + n_i16);
-    if (chains.empty() || n_i16 == 0) return QOA_OK;
+    if (recs.empty() || n_i16 == 0) return QOA_OK;
     if (!dec->stream) HIP_TRY(hipStreamCreateWithFlags(&dec->stream, hipStreamNonBlocking), QOA_DECODE_IO_ERROR);
-    // upload only the byte range the new frames span
-    size_t lo = dec->frames[first_frame].pos & ~(size_t)3, hi = dec->data.size();
-    for (auto &c : chains) c.frame_off -= lo;
-    HIP_TRY(dec->d_in.reserve(hi - lo + 8), QOA_DECODE_IO_ERROR);
+    // upload only the byte range the new frames span (frame positions are multiples of 8 by construction)
+    size_t lo = dec->frames[first_frame].pos & ~(size_t)7, hi = dec->data.size();
+    for (auto &c : recs) c.frame_off -= lo;
+    HIP_TRY(dec->d_in.reserve(hi - lo + 16), QOA_DECODE_IO_ERROR);
     HIP_TRY(dec->d_out.reserve(n_i16 * 2), QOA_DECODE_IO_ERROR);
-    HIP_TRY(dec->d_chains.reserve(chains.size() * sizeof(DecChain)), QOA_DECODE_IO_ERROR);
-    HIP_TRY(dec->d_mismatch.reserve(sizeof(unsigned)), QOA_DECODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(dec->d_in.p, dec->data.data() + lo, hi - lo, hipMemcpyHostToDevice, dec->stream),
             QOA_DECODE_IO_ERROR);
-    HIP_TRY(hipMemcpyAsync(dec->d_chains.p, chains.data(), chains.size() * sizeof(DecChain), hipMemcpyHostToDevice,
-                           dec->stream),
-            QOA_DECODE_IO_ERROR);
-    HIP_TRY(launch_decode((const uint8_t *)dec->d_in.p, (int16_t *)dec->d_out.p, (const DecChain *)dec->d_chains.p,
-                          (unsigned)chains.size(), (unsigned *)dec->d_mismatch.p, dec->stream),
-            QOA_DECODE_IO_ERROR);
+    HIP_TRY(dec->tables.upload(recs, dec->stream), QOA_DECODE_IO_ERROR);
+    HIP_TRY(dec->tables.run((const uint8_t *)dec->d_in.p, (int16_t *)dec->d_out.p, dec->stream), QOA_DECODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(dec->pcm.data() + base, dec->d_out.p, n_i16 * 2, hipMemcpyDeviceToHost, dec->stream),
             QOA_DECODE_IO_ERROR);
     HIP_TRY(hipStreamSynchronize(dec->stream), QOA_DECODE_IO_ERROR);

@@ -15,6 +15,10 @@ hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out,
 hipError_t launch_decode(const uint8_t *d_in, int16_t *d_out, const DecChain *d_chains, unsigned n_chains,
                          unsigned *d_mismatches, hipStream_t stream);
 
+// K2 for 1..8 channels: one DecChain entry per FRAME (its `channel` field is ignored), LDS-transposed output
+hipError_t launch_decode_frames(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames,
+                                unsigned n_frames, unsigned *d_mismatches, hipStream_t stream);
+
 // test hook: one slice, 16 candidates (device pointers; tot/fst/slice: 16 x u64, end_state: 16 x 8 x i32)
 hipError_t launch_debug_slice(const int32_t *d_state, const int32_t *d_samples, int len, int generic,
                               unsigned long long *d_tot, unsigned long long *d_fst, unsigned long long *d_slice,

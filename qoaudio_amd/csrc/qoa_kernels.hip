@@ -408,38 +408,87 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: decode (v1: one lane per (frame, channel) chain, direct global loads/stores)
+// K2: decode
+//
+// A decode chain is one (stream, frame, channel): the LMS state is re-seeded from every frame header
+// (src/lib.rs:270-281), so frames are independent.  One lane per chain, 20 steps per slice
+// (src/lib.rs:306-317): predict on full 32-bit multiplies (a hostile stream can drive decoder weights
+// anywhere), dequantise with the slice's four magnitudes (read once per slice from a 16-entry LDS table)
+// through v_perm_b32, clamp, LMS update.
+//
+// I/O.  Input: each lane reads its own 8-byte slice per row (channels of a frame are adjacent lanes, so a
+// wave touches 64/NCH lines per row and re-uses each line for 128/(8 NCH) rows out of L1/L2); the next
+// row's slice is loaded before the current one is decoded.  Output: int16 samples at stride NCH are
+// scattered 2 bytes at a time, which a global store cannot coalesce -- so every lane writes its samples
+// into an LDS image of the frame's interleaved PCM (R rows = R*20 sample-times per frame group), and the
+// wave then copies the image out as 16-byte pieces of contiguous global memory.  The group stride in LDS
+// is an odd number of dwords, so the 2-byte scatter is bank-conflict free across frames.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
-                                                         const DecChain *__restrict__ chains, unsigned n_chains,
-                                                         unsigned *__restrict__ mismatches) {
-    __shared__ uint2 s_mags[16];
+__device__ __forceinline__ void decode_init_lms(const uint8_t *f, unsigned channel, Lms &l) {
+    // 4 x i16 history, 4 x i16 weights, big-endian, sign-extended (src/lib.rs:271-281)
+    const unsigned *s = (const unsigned *)(f + 8 + 16 * (size_t)channel);
+    unsigned a = bswap32(s[0]), b = bswap32(s[1]), c = bswap32(s[2]), d = bswap32(s[3]);
+    l.h0 = (int)a >> 16; l.h1 = (int)(a << 16) >> 16; l.h2 = (int)b >> 16; l.h3 = (int)(b << 16) >> 16;
+    l.w0 = (int)c >> 16; l.w1 = (int)(c << 16) >> 16; l.w2 = (int)d >> 16; l.w3 = (int)(d << 16) >> 16;
+}
+
+// full 32-bit wrapping multiply-add in ONE instruction: the low dword of v_mad_u64_u32 (same issue rate as
+// v_mad_i32_i24 on gfx950, tools/ubench); the high dword is garbage and ignored.
+__device__ __forceinline__ unsigned long long mad32(int a, int b, unsigned long long acc) {
+    unsigned long long r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+
+// One decoded sample (src/lib.rs:307-316).  `code` is the 3-bit quantised residual.
+__device__ __forceinline__ int decode_step(Lms &l, int &s0, int &s1, int &s2, int &s3, unsigned code, unsigned dq_lo,
+                                           unsigned dq_hi) {
+    unsigned long long acc = (unsigned long long)(unsigned)mul32(l.w0, l.h0);
+    acc = mad32(l.w1, l.h1, acc);
+    acc = mad32(l.w2, l.h2, acc);
+    acc = mad32(l.w3, l.h3, acc);
+    int pred = (int)(unsigned)acc >> 13;
+    int sneg = -(int)(code & 1u);
+    unsigned sel = (code & 6u) * 0x0101u + 0x0c0c0100u;
+    int mag = (int)__builtin_amdgcn_perm(dq_hi, dq_lo, sel);
+    int deq = (mag ^ sneg) - sneg;
+    int recon = med3(pred + deq, -32768, 32767);
+    int delta = deq >> 4;
+    l.w0 = mad24(s0, delta, l.w0); l.w1 = mad24(s1, delta, l.w1);
+    l.w2 = mad24(s2, delta, l.w2); l.w3 = mad24(s3, delta, l.w3);
+    l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
+    s0 = s1; s1 = s2; s2 = s3; s3 = (recon >> 31) | 1;
+    return recon;
+}
+
+__device__ __forceinline__ void init_mag_table(uint2 *s_mags) {
     if (threadIdx.x < 16) {
         s_mags[threadIdx.x] = make_uint2((unsigned)c_mags[threadIdx.x][0] | ((unsigned)c_mags[threadIdx.x][1] << 16),
                                          (unsigned)c_mags[threadIdx.x][2] | ((unsigned)c_mags[threadIdx.x][3] << 16));
     }
     __syncthreads();
+}
+
+// K2 generic: any channel count (1..255), one lane per chain, direct 2-byte global stores.  Used for the
+// exotic streams only (more than 8 channels); everything else goes through qoa_decode_frames_kernel.
+__global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
+                                                         const DecChain *__restrict__ chains, unsigned n_chains,
+                                                         unsigned *__restrict__ mismatches) {
+    __shared__ uint2 s_mags[16];
+    init_mag_table(s_mags);
     const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_chains) return;
     const DecChain ch = chains[id];
     const uint8_t *f = in + ch.frame_off;
     const unsigned nch = ch.channels;
-
     if ((ch.expect_hi | ch.expect_lo) != 0 && ch.channel == 0) {
         unsigned hi = bswap32(*(const unsigned *)f), lo = bswap32(*(const unsigned *)(f + 4));
         if (hi != ch.expect_hi || lo != ch.expect_lo) atomicAdd(mismatches, 1u);
     }
-    // LMS state: 4 x i16 history, 4 x i16 weights, big-endian, sign-extended (src/lib.rs:271-281)
     Lms l;
-    {
-        const unsigned *s = (const unsigned *)(f + 8 + 16 * (size_t)ch.channel);
-        unsigned a = bswap32(s[0]), b = bswap32(s[1]), c = bswap32(s[2]), d = bswap32(s[3]);
-        l.h0 = (int)a >> 16; l.h1 = (int)(a << 16) >> 16; l.h2 = (int)b >> 16; l.h3 = (int)(b << 16) >> 16;
-        l.w0 = (int)c >> 16; l.w1 = (int)(c << 16) >> 16; l.w2 = (int)d >> 16; l.w3 = (int)(d << 16) >> 16;
-    }
+    decode_init_lms(f, ch.channel, l);
     int s0, s1, s2, s3;
     sign_mults(l, s0, s1, s2, s3);
-
     const uint8_t *sp = f + 8 + 16 * (size_t)nch + 8 * (size_t)ch.channel;
     int16_t *op = out + ch.out_off;
     unsigned remaining = ch.n_out;
@@ -450,33 +499,100 @@ __global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restri
         const uint2 dq = s_mags[hi >> 28];
         int16_t rec[20];
 #pragma unroll
-        for (int i = 0; i < 20; i++) {
-            // src/lib.rs:307-316.  Weights come from a 16-bit header and move <= 896 per step over at
-            // most 3277*20 steps?  No bound is assumed: full 32-bit multiplies keep this exact.
-            int pr = wadd(wadd(mul32(l.w0, l.h0), mul32(l.w1, l.h1)), wadd(mul32(l.w2, l.h2), mul32(l.w3, l.h3))) >> 13;
-            int code = (int)((slice >> (57 - 3 * i)) & 7u);
-            int sneg = -(code & 1);
-            unsigned sel = (unsigned)(code & 6) * 0x0101u + 0x0c0c0100u;
-            int mag = (int)__builtin_amdgcn_perm(dq.y, dq.x, sel);
-            int deq = (mag ^ sneg) - sneg;
-            int recon = med3(pr + deq, -32768, 32767);
-            rec[i] = (int16_t)recon;
-            int delta = deq >> 4;
-            l.w0 = mad24(s0, delta, l.w0); l.w1 = mad24(s1, delta, l.w1);
-            l.w2 = mad24(s2, delta, l.w2); l.w3 = mad24(s3, delta, l.w3);
-            l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
-            s0 = s1; s1 = s2; s2 = s3; s3 = (recon >> 31) | 1;
-        }
+        for (int i = 0; i < 20; i++)
+            rec[i] = (int16_t)decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
         const unsigned n = min(remaining, 20u); // tail: only `remaining` samples are exposed (src/lib.rs:320-328)
-        if (n == 20) {
 #pragma unroll
-            for (int i = 0; i < 20; i++) op[(size_t)i * nch] = rec[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 20; i++) if ((unsigned)i < n) op[(size_t)i * nch] = rec[i];
-        }
+        for (int i = 0; i < 20; i++) if ((unsigned)i < n) op[(size_t)i * nch] = rec[i];
         op += (size_t)20 * nch;
         remaining -= n;
+    }
+}
+
+// K2: NCH in 1..8, one table entry per FRAME, 64/NCH frames per wavefront, LDS-transposed output.
+template <int NCH, int R>
+__global__ void __launch_bounds__(256) qoa_decode_frames_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
+                                                                const DecChain *__restrict__ frames, unsigned n_frames,
+                                                                unsigned *__restrict__ mismatches) {
+    constexpr int FPW = 64 / NCH;               // frame groups per wavefront
+    constexpr int GS = R * 20 * NCH * 2;        // bytes of one group's PCM image (R rows)
+    constexpr int GSP = GS + 4;                 // odd dword stride: conflict-free 2-byte scatter across groups
+    constexpr int PPG = GS / 16;                // 16-byte pieces per group image
+    static_assert(GS % 16 == 0, "group image must be a whole number of 16-byte pieces");
+    struct GroupInfo { unsigned long long ptr; unsigned valid; unsigned pad; };
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[4][FPW * GSP + 12];
+    __shared__ __attribute__((aligned(16))) GroupInfo s_info[4][FPW];
+    __shared__ uint2 s_mags[16];
+    init_mag_table(s_mags);
+
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned g = lane / NCH, c = lane % NCH;
+    const unsigned frame_id = (blockIdx.x * 4u + wave) * FPW + g;
+    const bool valid = (g < (unsigned)FPW) && frame_id < n_frames;
+    DecChain fr;
+    if (valid) fr = frames[frame_id];
+    else { fr.frame_off = 0; fr.out_off = 0; fr.n_out = 0; fr.rows = 0; fr.channels = NCH; fr.channel = 0; fr.expect_hi = fr.expect_lo = 0; }
+    const unsigned rows = valid ? fr.rows : 0u;
+    const uint8_t *f = in + fr.frame_off;
+    Lms l = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        if ((fr.expect_hi | fr.expect_lo) != 0 && c == 0) {
+            unsigned hi = bswap32(*(const unsigned *)f), lo = bswap32(*(const unsigned *)(f + 4));
+            if (hi != fr.expect_hi || lo != fr.expect_lo) atomicAdd(mismatches, 1u);
+        }
+        decode_init_lms(f, c, l);
+    }
+    int s0, s1, s2, s3;
+    sign_mults(l, s0, s1, s2, s3);
+    const uint8_t *sp = f + 8 + 16 * NCH + 8 * c;
+    uint8_t *img = s_img[wave];
+    const unsigned my_img = g * GSP + c * 2;
+    uint2 cur = make_uint2(0, 0);
+    if (rows > 0) cur = *(const uint2 *)sp;
+
+    for (unsigned row0 = 0; __builtin_amdgcn_ballot_w64(row0 < rows) != 0ull; row0 += R) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned row = row0 + r;
+            uint2 nxt = make_uint2(0, 0);
+            if (row + 1 < rows) nxt = *(const uint2 *)(sp + (size_t)(row + 1) * (8 * NCH)); // prefetch
+            const unsigned hi = bswap32(cur.x), lo = bswap32(cur.y);
+            const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
+            const uint2 dq = s_mags[hi >> 28];
+#pragma unroll
+            for (int i = 0; i < 20; i++) {
+                int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
+                *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
+            }
+            cur = nxt;
+        }
+        // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step
+        if (c == 0 && g < (unsigned)FPW) {
+            unsigned done = row0 * 20u;
+            unsigned left = fr.n_out > done ? fr.n_out - done : 0u; // tail / truncated stream: src/lib.rs:320-328
+            GroupInfo gi;
+            gi.ptr = (unsigned long long)(out + fr.out_off + (size_t)done * NCH);
+            gi.valid = min(left, (unsigned)(R * 20)) * (NCH * 2);
+            gi.pad = 0;
+            s_info[wave][g] = gi;
+        }
+        for (unsigned p = lane; p < (unsigned)(FPW * PPG); p += 64) {
+            const unsigned gg = p / PPG, k = p % PPG;
+            const GroupInfo gi = s_info[wave][gg];
+            const unsigned off = k * 16;
+            if (off < gi.valid) {
+                const unsigned *src = (const unsigned *)(img + gg * GSP + off);
+                uint8_t *dst = (uint8_t *)gi.ptr + off;
+                if (off + 16 <= gi.valid) {
+                    typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(2)));
+                    u4_unaligned v = {src[0], src[1], src[2], src[3]};
+                    *(u4_unaligned *)dst = v;
+                } else {
+                    const unsigned n16 = (gi.valid - off) >> 1;
+                    for (unsigned q = 0; q < n16; q++) ((int16_t *)dst)[q] = ((const int16_t *)src)[q];
+                }
+            }
+        }
     }
 }
 
@@ -526,6 +642,26 @@ hipError_t launch_decode(const uint8_t *in, int16_t *out, const DecChain *chains
     if (n == 0) return hipSuccess;
     dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(qoa_decode_kernel, g, b, 0, stream, in, out, chains, n, mismatches);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_frames(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
+                                unsigned *mismatches, hipStream_t stream) {
+    if (n_frames == 0) return hipSuccess;
+    constexpr int R = 4;
+    dim3 b(256);
+#define QOA_LAUNCH(N)                                                                                              \
+    case N: {                                                                                                      \
+        unsigned per_block = 4u * (64u / N);                                                                       \
+        dim3 g((n_frames + per_block - 1) / per_block);                                                            \
+        hipLaunchKernelGGL((qoa_decode_frames_kernel<N, R>), g, b, 0, stream, in, out, frames, n_frames, mismatches); \
+        break;                                                                                                     \
+    }
+    switch (nch) {
+        QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef QOA_LAUNCH
     return hipGetLastError();
 }
 
