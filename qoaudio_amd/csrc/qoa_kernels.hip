@@ -66,87 +66,125 @@ __device__ __forceinline__ int sgn(int v) {
     return r;
 }
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-// min over the 16 lanes of a DPP row, result in every lane (min is idempotent, so rotations suffice)
-__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
-    v = min(v, dpp<0x128>(v)); // row_ror:8
-    v = min(v, dpp<0x124>(v)); // row_ror:4
-    v = min(v, dpp<0x122>(v)); // row_ror:2
-    v = min(v, dpp<0x121>(v)); // row_ror:1
-    return v;
-}
-
 struct Lms {
     int h0, h1, h2, h3; // history, oldest first (src/lib.rs:72)
     int w0, w1, w2, w3; // weights (src/lib.rs:73)
 };
 
+// full 32-bit wrapping multiply-add in ONE instruction: the low dword of v_mad_u64_u32.  Measured on gfx950
+// (tools/ubench): same issue cost as v_mad_i32_i24 and as v_mul_lo_u32, so the dot products need no 24-bit
+// operand guard and no second code path.  The high dword is garbage and ignored.
+__device__ __forceinline__ unsigned long long mad32(int a, int b, unsigned long long acc) {
+    unsigned long long r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+// acc(u64) += (i64)a * a : the rank sum of squared errors in one instruction
+__device__ __forceinline__ unsigned long long mad_sq64(int a, unsigned long long acc) {
+    unsigned long long r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(a), "v"(acc) : "vcc");
+    return r;
+}
+
 struct CandResult {
-    Lms lms;              // end state of this candidate
-    unsigned e_lo, e_hi;  // sum of err^2 (u64)
-    unsigned pen;         // sum of penalty^2 (fits u32: 20 * 5888^2)
-    unsigned e0, p0;      // first-sample err^2 and penalty^2
-    unsigned s_hi, s_lo;  // packed 64-bit slice, tail already left-aligned
+    Lms lms;                 // end state of this candidate
+    unsigned long long e;    // sum of err^2
+    unsigned pen;            // sum of penalty^2 (fits u32: 20 * 5888^2)
+    unsigned aerr0;          // |err| of the first sample: orders the first-sample ranks (the first-sample
+                             // penalty is the same for all 16 candidates, they share the entry weights)
+    unsigned s_hi, s_lo;     // packed 64-bit slice, tail already left-aligned
 };
 
-// One candidate-sample step (src/lib.rs:566-584).  MUL is mul24 on the fast path.
-//   dq_lo/dq_hi: the lane's four dequant magnitudes packed 2x16 bit; recip: its reciprocal.
-// Quantiser closed form (unit-tested exhaustively against QOA_QUANT_TAB/QOA_DEQUANT_TAB):
-//   c = clamp(scaled,-8,8); level = min(|c|>>1,3); code = 2*level + (c<0); dequant = +-mag[level].
-template <bool FAST>
-__device__ __forceinline__ void cand_step(int smp, int recip, unsigned dq_lo, unsigned dq_hi, Lms &l, int &s0,
-                                          int &s1, int &s2, int &s3, unsigned &e2, unsigned &p2, int &code) {
-    // predict: ((w0h0 + w1h1) + (w2h2 + w3h3)) >> 13, wrapping   (src/lib.rs:811-813)
-    // weights penalty: max(0, ((w0w0 + w1w1 + w2w2 + w3w3) >> 18) - 0x8ff)   (src/lib.rs:814-817)
-    // qoa_div: ((res * recip + 2^15) >> 16) + sgn(res) - sgn(n)            (src/lib.rs:613-617)
-    int p, q, res, n, pred;
-    if (FAST) {
-        p = mad24(l.w3, l.h3, mad24(l.w2, l.h2, mad24(l.w1, l.h1, mul24(l.w0, l.h0))));
-        q = mad24(l.w3, l.w3, mad24(l.w2, l.w2, mad24(l.w1, l.w1, mul24(l.w0, l.w0))));
-        pred = p >> 13;
-        res = smp - pred;
-        n = mad24(res, recip, 1 << 15) >> 16;
-    } else {
-        p = wadd(wadd(mul32(l.w0, l.h0), mul32(l.w1, l.h1)), wadd(mul32(l.w2, l.h2), mul32(l.w3, l.h3)));
-        q = wadd(wadd(mul32(l.w0, l.w0), mul32(l.w1, l.w1)), wadd(mul32(l.w2, l.w2), mul32(l.w3, l.w3)));
-        pred = p >> 13;
-        res = smp - pred;
-        n = wadd(mul32(res, recip), 1 << 15) >> 16;
-    }
-    int pen = max((q >> 18) - 0x8ff, 0);
-    p2 = (unsigned)mul24(pen, pen); // pen <= 5888
-    int scaled = n + sgn(res) - sgn(n);
-    // quantise + dequantise
-    int sneg = scaled >> 31;
-    int a = (scaled ^ sneg) - sneg;
-    int l2 = min(a, 7) & 6; // 2*level
-    unsigned sel = (unsigned)l2 * 0x0101u + 0x0c0c0100u;
-    int mag = (int)__builtin_amdgcn_perm(dq_hi, dq_lo, sel);
-    int deq = (mag ^ sneg) - sneg;
-    code = l2 - sneg;
-    int recon = med3(pred + deq, -32768, 32767);
-    int err = smp - recon;
-    e2 = (unsigned)mul24(err, err); // |err| <= 65535: exact in 32 bits
-    // LMS update (src/lib.rs:821-828): w_i += sign(h_i) * (deq >> 4); s_i = +-1 travels with h_i
-    int delta = deq >> 4;
-    l.w0 = mad24(s0, delta, l.w0); // |delta| <= 896, s = +-1: always 24-bit safe; the add wraps
-    l.w1 = mad24(s1, delta, l.w1);
-    l.w2 = mad24(s2, delta, l.w2);
-    l.w3 = mad24(s3, delta, l.w3);
+// One candidate-sample step (src/lib.rs:566-584) as ONE hand-written instruction block:
+// 42 VALU instructions.  The kernel is issue-bound at one wave per SIMD (~4.7 cycles per instruction whatever
+// it is, tools/ubench), so instruction COUNT is the cost; written in C++ the same step compiles to 43-44
+// instructions plus an s_nop after every one of its 6-7 inline-asm helpers (hipcc pads each asm boundary).
+//
+//   predict   ((w0h0 + w1h1) + (w2h2 + w3h3)) >> 13, wrapping                      src/lib.rs:811-813
+//   penalty   max(0, ((w0w0 + w1w1 + w2w2 + w3w3) >> 18) - 0x8ff), squared, summed    src/lib.rs:814-817
+//   qoa_div   ((res * recip + 2^15) >> 16) + sgn(res) - sgn(n)                     src/lib.rs:613-617
+//   quantiser c = clamp(scaled,-8,8); level = min(|c|>>1,3); code = 2*level + (c<0); dequant = +-mag[level]
+//             (closed form of QOA_QUANT_TAB / QOA_DEQUANT_TAB, verified exhaustively in tests/test_capi_host.py;
+//             the lane's four magnitudes are packed in dq_lo/dq_hi and selected by v_perm_b32)
+//   update    w_i += sign(h_i) * (dequant >> 4), s_i = +-1 travels with h_i         src/lib.rs:821-828
+//
+// Dot products use v_mul_lo_u32 + v_mad_u64_u32 (low dword = full 32-bit wrapping multiply-add; same issue cost
+// as the 24-bit forms on gfx950), so weights need no range guard.  v_mad_i32_i24 is used only where the operands
+// provably fit 24 bits: residual (|r| < 2^19) x reciprocal (<= 2^16), penalty (<= 5888), +-1 x (dequant >> 4).
+// v[124:127] are scratch pairs for the two dot products (a 64-bit asm operand has no sub-register syntax).
+struct StepConst {
+    int recip;          // this lane's reciprocal
+    unsigned dq_lo, dq_hi; // this lane's dequant magnitudes, 2 x 16 bit each
+    unsigned selbase;   // 0x0c0c0100: v_perm selector for level 0
+    int hi;             // 32767
+};
+
+__device__ __forceinline__ void cand_step(int smp, const StepConst &k, Lms &l, int &s0, int &s1, int &s2, int &s3,
+                                          unsigned long long &e, unsigned &pen_sum, unsigned &acc, int &err_out) {
+    int nw0, nw1, nw2, nw3, recon, ns3, err, t, u, sneg;
+    asm("v_mul_lo_u32 v124, %[w0], %[h0]\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, %[w1], %[h1], v[124:125]\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, %[w2], %[h2], v[124:125]\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, %[w3], %[h3], v[124:125]\n\t"
+        "v_ashrrev_i32 v124, 13, v124\n\t"                     // v124 = predicted
+        "v_mul_lo_u32 v126, %[w0], %[w0]\n\t"
+        "v_mad_u64_u32 v[126:127], vcc, %[w1], %[w1], v[126:127]\n\t"
+        "v_mad_u64_u32 v[126:127], vcc, %[w2], %[w2], v[126:127]\n\t"
+        "v_mad_u64_u32 v[126:127], vcc, %[w3], %[w3], v[126:127]\n\t"
+        "v_ashrrev_i32 v126, 18, v126\n\t"
+        "v_max_i32 v126, 0x8ff, v126\n\t"
+        "v_add_u32 v126, 0xfffff701, v126\n\t"                 // penalty = max(x - 0x8ff, 0)
+        "v_mad_i32_i24 %[pen], v126, v126, %[pen]\n\t"
+        "v_sub_u32 %[t], %[smp], v124\n\t"                     // residual
+        "v_mad_i32_i24 %[u], %[t], %[recip], %[rnd]\n\t"
+        "v_med3_i32 %[t], %[t], -1, 1\n\t"                     // sgn(residual)
+        "v_ashrrev_i32 %[u], 16, %[u]\n\t"                     // n
+        "v_add_u32 %[t], %[u], %[t]\n\t"
+        "v_med3_i32 %[u], %[u], -1, 1\n\t"                     // sgn(n)
+        "v_sub_u32 %[u], %[t], %[u]\n\t"                       // scaled
+        "v_ashrrev_i32 %[sneg], 31, %[u]\n\t"
+        "v_sub_u32 %[t], 0, %[u]\n\t"
+        "v_max_i32 %[t], %[u], %[t]\n\t"                       // |scaled|
+        "v_min_i32 %[t], 7, %[t]\n\t"
+        "v_and_b32 %[t], 6, %[t]\n\t"                          // 2*level
+        "v_lshl_add_u32 %[acc], %[acc], 3, %[t]\n\t"
+        "v_sub_u32 %[acc], %[acc], %[sneg]\n\t"                // acc = acc<<3 | code
+        "v_mad_u32_u24 %[t], %[t], %[c101], %[selb]\n\t"
+        "v_perm_b32 %[t], %[dqhi], %[dqlo], %[t]\n\t"          // magnitude
+        "v_xor_b32 %[t], %[t], %[sneg]\n\t"
+        "v_sub_u32 %[t], %[t], %[sneg]\n\t"                    // dequantised
+        "v_add_u32 %[recon], %[t], v124\n\t"
+        "v_med3_i32 %[recon], %[recon], %[lo], %[hi]\n\t"      // reconstructed
+        "v_sub_u32 %[err], %[smp], %[recon]\n\t"
+        "v_mad_i64_i32 %[e], vcc, %[err], %[err], %[e]\n\t"    // rank += err^2
+        "v_ashrrev_i32 %[t], 4, %[t]\n\t"                      // delta
+        "v_mad_i32_i24 %[nw0], %[s0], %[t], %[w0]\n\t"
+        "v_mad_i32_i24 %[nw1], %[s1], %[t], %[w1]\n\t"
+        "v_mad_i32_i24 %[nw2], %[s2], %[t], %[w2]\n\t"
+        "v_mad_i32_i24 %[nw3], %[s3], %[t], %[w3]\n\t"
+        "v_ashrrev_i32 %[ns3], 31, %[recon]\n\t"
+        "v_or_b32 %[ns3], 1, %[ns3]"
+        : [nw0] "=&v"(nw0), [nw1] "=&v"(nw1), [nw2] "=&v"(nw2), [nw3] "=&v"(nw3), [recon] "=&v"(recon),
+          [ns3] "=&v"(ns3), [err] "=&v"(err), [t] "=&v"(t), [u] "=&v"(u), [sneg] "=&v"(sneg), [e] "+v"(e),
+          [pen] "+v"(pen_sum), [acc] "+v"(acc)
+        : [w0] "v"(l.w0), [w1] "v"(l.w1), [w2] "v"(l.w2), [w3] "v"(l.w3), [h0] "v"(l.h0), [h1] "v"(l.h1),
+          [h2] "v"(l.h2), [h3] "v"(l.h3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [smp] "v"(smp),
+          [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi),
+          [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768)
+        : "vcc", "v124", "v125", "v126", "v127");
+    l.w0 = nw0; l.w1 = nw1; l.w2 = nw2; l.w3 = nw3;
     l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
-    s0 = s1; s1 = s2; s2 = s3; s3 = (recon >> 31) | 1;
+    s0 = s1; s1 = s2; s2 = s3; s3 = ns3;
+    err_out = err;
 }
 
 __device__ __forceinline__ void sign_mults(const Lms &l, int &s0, int &s1, int &s2, int &s3) {
     s0 = (l.h0 >> 31) | 1; s1 = (l.h1 >> 31) | 1; s2 = (l.h2 >> 31) | 1; s3 = (l.h3 >> 31) | 1;
 }
 
-// Fast path: a full 20-sample slice, 24-bit multiplies, fully unrolled (history shift = renaming).
-__device__ __forceinline__ void run_slice_fast(const int (&smp)[20], int sf, int recip, unsigned dq_lo, unsigned dq_hi,
-                                               const Lms &entry, CandResult &r) {
+// A full 20-sample slice, fully unrolled (the history shift is register renaming).
+__device__ __forceinline__ void run_slice_full(const int (&smp)[20], int sf, const StepConst &k, const Lms &entry,
+                                               CandResult &r) {
     Lms l = entry;
     int s0, s1, s2, s3;
     sign_mults(l, s0, s1, s2, s3);
@@ -154,30 +192,23 @@ __device__ __forceinline__ void run_slice_fast(const int (&smp)[20], int sf, int
     unsigned pen = 0, acc_a = 0, acc_b = 0;
 #pragma unroll
     for (int i = 0; i < 20; i++) {
-        unsigned e2, p2;
-        int code;
-        cand_step<true>(smp[i], recip, dq_lo, dq_hi, l, s0, s1, s2, s3, e2, p2, code);
-        if (i == 0) { r.e0 = e2; r.p0 = p2; }
-        e += e2;
-        pen += p2;
-        if (i < 10) acc_a = (acc_a << 3) + (unsigned)code;
-        else acc_b = (acc_b << 3) + (unsigned)code;
+        int err;
+        cand_step(smp[i], k, l, s0, s1, s2, s3, e, pen, i < 10 ? acc_a : acc_b, err);
+        if (i == 0) r.aerr0 = uabs(err);
     }
     r.lms = l;
-    r.e_lo = (unsigned)e;
-    r.e_hi = (unsigned)(e >> 32);
+    r.e = e;
     r.pen = pen;
     // slice = sf<<60 | codes 0..9 <<30 | codes 10..19   (src/lib.rs:549,560,584)
     r.s_hi = ((unsigned)sf << 28) | (acc_a >> 2);
     r.s_lo = (acc_a << 30) | acc_b;
 }
 
-// Generic path: any slice length 1..20, full 32-bit multiplies.  Rolled loop; the sample window is
-// shifted through registers so nothing is runtime-indexed (a runtime index would put the array in
-// scratch).  Codes are placed at their final bit positions, which is the reference's tail shift
-// (src/lib.rs:485-487) for free.  Rare: the last slice of a clip, or weights beyond 24 bits.
-__device__ __forceinline__ void run_slice_generic(const int (&smp)[20], int len, int sf, int recip, unsigned dq_lo,
-                                                  unsigned dq_hi, const Lms &entry, CandResult &r) {
+// Any slice length 1..20 (the last slice of a clip).  Rolled loop; the sample window is shifted through
+// registers so nothing is runtime-indexed (a runtime index would put the array in scratch).  Codes are
+// placed at their final bit positions, which is the reference's tail shift (src/lib.rs:485-487) for free.
+__device__ __forceinline__ void run_slice_tail(const int (&smp)[20], int len, int sf, const StepConst &k,
+                                               const Lms &entry, CandResult &r) {
     Lms l = entry;
     int s0, s1, s2, s3;
     sign_mults(l, s0, s1, s2, s3);
@@ -186,25 +217,47 @@ __device__ __forceinline__ void run_slice_generic(const int (&smp)[20], int len,
     int t[20];
 #pragma unroll
     for (int j = 0; j < 20; j++) t[j] = smp[j];
-    r.e0 = 0; r.p0 = 0;
+    r.aerr0 = 0;
 #pragma unroll 1
     for (int i = 0; i < len; i++) {
-        unsigned e2, p2;
-        int code;
-        cand_step<false>(t[0], recip, dq_lo, dq_hi, l, s0, s1, s2, s3, e2, p2, code);
+        int err;
+        unsigned code = 0;
+        cand_step(t[0], k, l, s0, s1, s2, s3, e, pen, code, err);
 #pragma unroll
         for (int j = 0; j < 19; j++) t[j] = t[j + 1];
-        if (i == 0) { r.e0 = e2; r.p0 = p2; }
-        e += e2;
-        pen += p2;
-        slice |= (unsigned long long)(unsigned)code << (57 - 3 * i);
+        if (i == 0) r.aerr0 = uabs(err);
+        slice |= (unsigned long long)code << (57 - 3 * i);
     }
     r.lms = l;
-    r.e_lo = (unsigned)e;
-    r.e_hi = (unsigned)(e >> 32);
+    r.e = e;
     r.pen = pen;
     r.s_hi = (unsigned)(slice >> 32);
     r.s_lo = (unsigned)slice;
+}
+
+// min over the 16 lanes of a DPP row, result in every lane: 4 fused v_min_u32_dpp (row_ror 8,4,2,1).
+// The s_nop 1 in front of each is the VALU-write -> DPP-read hazard (2 wait states), which hipcc does not
+// insert inside an asm statement.
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
+// Winner of a slice = argmin (total rank, first-sample rank, sf): the closed form of the reference's
+// rank-sorted candidate order with its two early exits (src/lib.rs:516-593).  total < 2^37; first-sample
+// ranks order like |err0| (16 bits) -- two 32-bit keys: tot>>5, then tot[4:0] : |err0| : sf.
+__device__ __forceinline__ unsigned pick_winner(const CandResult &r, int sf) {
+    const unsigned long long tot = r.e + r.pen;
+    const unsigned t_lo = (unsigned)tot, t_hi = (unsigned)(tot >> 32);
+    const unsigned k1 = __builtin_amdgcn_alignbit(t_hi, t_lo, 5);
+    unsigned k2 = ((t_lo & 31u) << 20) | (r.aerr0 << 4) | (unsigned)sf;
+    const unsigned m1 = row_min_u32(k1);
+    k2 = (k1 == m1) ? k2 : 0xffffffffu;
+    return row_min_u32(k2) & 15u;
 }
 
 __device__ __forceinline__ unsigned bswap32(unsigned v) { return __builtin_bswap32(v); }
@@ -214,20 +267,22 @@ __device__ __forceinline__ unsigned bswap32(unsigned v) { return __builtin_bswap
 //
 // Memory schedule.  All global-memory traffic of a chain happens once per BLOCK of 16 slices
 // (320 sample-times), in straight-line code at the block top: lane j of the chain's 16-lane row
-// loads the 20 samples of slice 16*blk+j for the NEXT block (20 x global_load_sshort, addresses
-// clamped instead of branched), and stores the 8-byte slice it staged for row 16*(blk-1)+j of the
-// PREVIOUS block (16 lanes x 8 B = one 128-B line per row for mono).  Inside a block there is no
-// vector-memory instruction at all, so no s_waitcnt vmcnt can land on the ~1.4 us serial slice
-// step; samples reach the 16 candidate lanes through ds_bpermute (LDS crossbar, no LDS memory).
-// A frame is exactly 16 blocks, so frame headers / LMS dumps are written at block tops too.
+// loads the 20 samples of slice 16*(blk+1)+j for the NEXT block (20 x global_load_sshort, addresses
+// clamped instead of branched), parks the 20 samples it loaded one block earlier in a wave-private
+// LDS tile [chain][slice j][20] (5 x ds_write_b128), and stores the 8-byte slice it kept for row
+// 16*(blk-1)+j of the PREVIOUS block.  Inside a block there is no vector-memory instruction at all,
+// so no s_waitcnt vmcnt can land on the serial slice step; the 16 candidate lanes of a chain fetch
+// a slice's 20 samples with 5 broadcast ds_read_b128.  A frame is exactly 16 blocks, so frame
+// headers / LMS dumps are written at block tops too.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlockSlices = 16;
+constexpr int kTileInts = kBlockSlices * 20 + 4; // +16 B: the 4 chain tiles of a wave start on different banks
 
 template <int NCH>
 __device__ __forceinline__ void load_block_lane(const int16_t *__restrict__ p, unsigned slice_idx, unsigned samples,
                                                 int (&v)[20]) {
     // p = this channel's sample 0; sample t is p[t*NCH].  Indices past the clip end are clamped to its
-    // last sample: the values are never used (the generic path stops at the slice length).
+    // last sample: the values are never used (the tail path stops at the slice length).
     // Branch-free on purpose: an if/else here makes the 20 values a phi of vectors, which hipcc keeps
     // as a 32-register tuple and guards with vmcnt waits inside the slice loop.
     const unsigned long long base = (unsigned long long)slice_idx * 20u;
@@ -240,24 +295,30 @@ template <int CPW, int NCH>
 __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restrict__ pcm, uint8_t *__restrict__ out,
                                                          const EncChain *__restrict__ chains, unsigned n_chains,
                                                          int32_t *__restrict__ lms_state, unsigned flags) {
+    __shared__ __attribute__((aligned(16))) int s_smp[4][CPW][kTileInts];
     const unsigned lane = threadIdx.x & 63u;
     const unsigned grp = lane >> 4;
-    if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle (free: issue-bound kernel)
-    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle
+    const unsigned wave_in_block = threadIdx.x >> 6;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const unsigned chain_id = wave * CPW + grp;
     if (chain_id >= n_chains) return;
     const int sf = (int)(lane & 15u);
     const unsigned row_base = lane & ~15u;
+    int *tile = s_smp[wave_in_block][grp];
 
     const EncChain ch = chains[chain_id];
     const int16_t *p = pcm + ch.pcm_off;
     const unsigned samples = ch.samples;
     const unsigned nslices = (samples + 19u) / 20u;
     const unsigned nblocks = (nslices + kBlockSlices - 1) / kBlockSlices;
-    const int recip = c_recip[sf];
-    const unsigned dq_lo = (unsigned)c_mags[sf][0] | ((unsigned)c_mags[sf][1] << 16);
-    const unsigned dq_hi = (unsigned)c_mags[sf][2] | ((unsigned)c_mags[sf][3] << 16);
-    const bool force_generic = (flags & 1u) != 0;
+    StepConst kc;
+    kc.recip = c_recip[sf];
+    kc.dq_lo = (unsigned)c_mags[sf][0] | ((unsigned)c_mags[sf][1] << 16);
+    kc.dq_hi = (unsigned)c_mags[sf][2] | ((unsigned)c_mags[sf][3] << 16);
+    kc.selbase = 0x0c0c0100u;
+    kc.hi = 32767;
+    const bool force_tail_path = (flags & 1u) != 0;
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -275,21 +336,18 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         o += 8;
     }
     constexpr unsigned kFrameBytes = 8 + 16 * NCH + 8 * kSlicesPerFrame * NCH; // a full frame
-    constexpr unsigned kWLimit = (1u << 23) - 20u * 896u;
 
-    int pre[20];          // lane j: samples of slice 16*(blk+1)+j, in flight during block blk
+    int pre[20];                       // lane j: samples of slice 16*(blk+1)+j, in flight during block blk
     unsigned keep_hi = 0, keep_lo = 0; // lane j: finished slice of row 16*blk+j
     load_block_lane<NCH>(p, (unsigned)sf, samples, pre);
 
     for (unsigned blk = 0; blk < nblocks; blk++) {
         // ---------------- block top: every vector-memory instruction of the loop lives here ----------------
-        // The copy is an opaque v_mov on purpose: it pins the vmcnt wait for the prefetched samples HERE,
-        // before this block's stores and loads are issued.  With a plain copy hipcc forwards the load
-        // registers into the slice loop and guards every ds_bpermute there with a counted vmcnt that
-        // also waits for the block-top stores.
-        int mine[20];
+        {
+            int4 *dst = (int4 *)(tile + sf * 20); // needs the prefetched samples: the only vmcnt wait of the loop
 #pragma unroll
-        for (int i = 0; i < 20; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(mine[i]) : "v"(pre[i]));
+            for (int q = 0; q < 5; q++) dst[q] = make_int4(pre[4 * q], pre[4 * q + 1], pre[4 * q + 2], pre[4 * q + 3]);
+        }
         if (blk > 0) { // flush the previous block's 16 slices (always a full block)
             const unsigned k = (blk - 1) * kBlockSlices + (unsigned)sf;
             uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
@@ -317,49 +375,39 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         const unsigned k0 = blk * kBlockSlices;
         const unsigned nj = min(nslices - k0, (unsigned)kBlockSlices);
         for (unsigned j = 0; j < nj; j++) {
-            const int from = (int)((row_base | j) << 2);
             int smp[20];
+            {
+                const int4 *src = (const int4 *)(tile + j * 20); // same address in all 16 lanes: LDS broadcast
 #pragma unroll
-            for (int i = 0; i < 20; i++) smp[i] = __builtin_amdgcn_ds_bpermute(from, mine[i]);
-
+                for (int q = 0; q < 5; q++) {
+                    const int4 v = src[q];
+                    smp[4 * q] = v.x; smp[4 * q + 1] = v.y; smp[4 * q + 2] = v.z; smp[4 * q + 3] = v.w;
+                }
+            }
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);
-            const unsigned wmax = max(max(uabs(st.w0), uabs(st.w1)), max(uabs(st.w2), uabs(st.w3)));
-            const bool fast_ok = (len == 20) && (wmax < kWLimit) && !force_generic;
+            const bool full = (len == 20) && !force_tail_path;
 
             CandResult r;
-            if (__builtin_amdgcn_ballot_w64(!fast_ok) == 0ull) {
-                run_slice_fast(smp, sf, recip, dq_lo, dq_hi, st, r);
+            if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
+                run_slice_full(smp, sf, kc, st, r);
             } else {
-                run_slice_generic(smp, len, sf, recip, dq_lo, dq_hi, st, r);
+                run_slice_tail(smp, len, sf, kc, st, r);
             }
-
-            // winner = argmin (total, first, sf): three 32-bit keys, most significant first.
-            unsigned long long tot = (((unsigned long long)r.e_hi << 32) | r.e_lo) + r.pen;
-            unsigned long long fst = (unsigned long long)r.e0 + r.p0;
-            unsigned t_lo = (unsigned)tot, t_hi = (unsigned)(tot >> 32);
-            unsigned f_lo = (unsigned)fst, f_hi = (unsigned)(fst >> 32);
-            unsigned k1 = __builtin_amdgcn_alignbit(t_hi, t_lo, 5);                // tot >> 5  (tot < 2^37)
-            unsigned k2 = (t_lo << 27) | __builtin_amdgcn_alignbit(f_hi, f_lo, 6); // tot[4:0] : fst >> 6 (fst < 2^33)
-            unsigned k3 = ((f_lo & 63u) << 4) | (unsigned)sf;                      // fst[5:0] : sf
-            unsigned m1 = row_min_u32(k1);
-            k2 = (k1 == m1) ? k2 : 0xffffffffu;
-            unsigned m2 = row_min_u32(k2);
-            k3 = (k2 == m2) ? k3 : 0xffffffffu;
-            unsigned m3 = row_min_u32(k3);
-            const int src = (int)((row_base | (m3 & 15u)) << 2);
+            const unsigned win = pick_winner(r, sf);
+            const int src_lane = (int)((row_base | win) << 2);
 
             // LMS carry: every lane of the row takes the winner's end state (src/lib.rs:482);
             // lane j keeps the winner's slice for the block flush (src/lib.rs:488).
-            unsigned w_hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)r.s_hi);
-            unsigned w_lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)r.s_lo);
-            st.h0 = __builtin_amdgcn_ds_bpermute(src, r.lms.h0);
-            st.h1 = __builtin_amdgcn_ds_bpermute(src, r.lms.h1);
-            st.h2 = __builtin_amdgcn_ds_bpermute(src, r.lms.h2);
-            st.h3 = __builtin_amdgcn_ds_bpermute(src, r.lms.h3);
-            st.w0 = __builtin_amdgcn_ds_bpermute(src, r.lms.w0);
-            st.w1 = __builtin_amdgcn_ds_bpermute(src, r.lms.w1);
-            st.w2 = __builtin_amdgcn_ds_bpermute(src, r.lms.w2);
-            st.w3 = __builtin_amdgcn_ds_bpermute(src, r.lms.w3);
+            unsigned w_hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)r.s_hi);
+            unsigned w_lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)r.s_lo);
+            st.h0 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.h0);
+            st.h1 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.h1);
+            st.h2 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.h2);
+            st.h3 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.h3);
+            st.w0 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w0);
+            st.w1 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w1);
+            st.w2 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w2);
+            st.w3 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w3);
             if ((unsigned)sf == j) { keep_hi = w_hi; keep_lo = w_lo; }
         }
     }
@@ -388,9 +436,12 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
                                        int32_t *__restrict__ end_state) {
     const int sf = (int)(threadIdx.x & 15u);
     if (threadIdx.x >= 16) return;
-    const int recip = c_recip[sf];
-    const unsigned dq_lo = (unsigned)c_mags[sf][0] | ((unsigned)c_mags[sf][1] << 16);
-    const unsigned dq_hi = (unsigned)c_mags[sf][2] | ((unsigned)c_mags[sf][3] << 16);
+    StepConst kc;
+    kc.recip = c_recip[sf];
+    kc.dq_lo = (unsigned)c_mags[sf][0] | ((unsigned)c_mags[sf][1] << 16);
+    kc.dq_hi = (unsigned)c_mags[sf][2] | ((unsigned)c_mags[sf][3] << 16);
+    kc.selbase = 0x0c0c0100u;
+    kc.hi = 32767;
     Lms st;
     st.h0 = state[0]; st.h1 = state[1]; st.h2 = state[2]; st.h3 = state[3];
     st.w0 = state[4]; st.w1 = state[5]; st.w2 = state[6]; st.w3 = state[7];
@@ -398,10 +449,10 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 #pragma unroll
     for (int i = 0; i < 20; i++) smp[i] = samples[i];
     CandResult r;
-    if (generic || len != 20) run_slice_generic(smp, len, sf, recip, dq_lo, dq_hi, st, r);
-    else run_slice_fast(smp, sf, recip, dq_lo, dq_hi, st, r);
-    tot[sf] = (((unsigned long long)r.e_hi << 32) | r.e_lo) + r.pen;
-    fst[sf] = (unsigned long long)r.e0 + r.p0;
+    if (generic || len != 20) run_slice_tail(smp, len, sf, kc, st, r);
+    else run_slice_full(smp, sf, kc, st, r);
+    tot[sf] = r.e + r.pen;
+    fst[sf] = ((unsigned long long)pick_winner(r, sf) << 32) | r.aerr0; // [63:32] winner of the row, [31:0] |err0|
     slice[sf] = ((unsigned long long)r.s_hi << 32) | r.s_lo;
     int32_t *o = end_state + sf * 8;
     o[0] = r.lms.h0; o[1] = r.lms.h1; o[2] = r.lms.h2; o[3] = r.lms.h3;
@@ -431,14 +482,6 @@ __device__ __forceinline__ void decode_init_lms(const uint8_t *f, unsigned chann
     unsigned a = bswap32(s[0]), b = bswap32(s[1]), c = bswap32(s[2]), d = bswap32(s[3]);
     l.h0 = (int)a >> 16; l.h1 = (int)(a << 16) >> 16; l.h2 = (int)b >> 16; l.h3 = (int)(b << 16) >> 16;
     l.w0 = (int)c >> 16; l.w1 = (int)(c << 16) >> 16; l.w2 = (int)d >> 16; l.w3 = (int)(d << 16) >> 16;
-}
-
-// full 32-bit wrapping multiply-add in ONE instruction: the low dword of v_mad_u64_u32 (same issue rate as
-// v_mad_i32_i24 on gfx950, tools/ubench); the high dword is garbage and ignored.
-__device__ __forceinline__ unsigned long long mad32(int a, int b, unsigned long long acc) {
-    unsigned long long r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
-    return r;
 }
 
 // One decoded sample (src/lib.rs:307-316).  `code` is the 3-bit quantised residual.

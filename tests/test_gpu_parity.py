@@ -331,7 +331,10 @@ def _gpu_slice(state, smp, generic=0):
     rc = _lib.lib().qoa_debug_encode_slice(st.ctypes.data, s.ctypes.data, len(s), generic, tot.ctypes.data,
                                            fst.ctypes.data, sl.ctypes.data, es.ctypes.data)
     assert rc == 0
-    return [int(v) for v in tot], [int(v) for v in fst], [int(v) for v in sl], es
+    # fst[i] = (the device's own winner of the row << 32) | |err0| of candidate i
+    wins = {int(v) >> 32 for v in fst}
+    assert len(wins) == 1, "every lane must agree on the winner"
+    return [int(v) for v in tot], [int(v) & 0xffffffff for v in fst], [int(v) for v in sl], es, wins.pop()
 
 
 def test_kat2_slice_search_lane_by_lane(gpu, oracle):
@@ -342,10 +345,10 @@ def test_kat2_slice_search_lane_by_lane(gpu, oracle):
     want = [522117267, 525200405, 119383785, 43336318, 1587308, 1582747, 1887874, 1946592, 2513046, 3221590, 4272064,
             3964616, 6487859, 13440220, 24107150, 16356911]
     for generic in (0, 1):
-        tot, fst, sl, es = _gpu_slice(state, smp, generic)
+        tot, aerr0, sl, es, dev_win = _gpu_slice(state, smp, generic)
         assert tot == want
-        win = min((tot[i], fst[i], i) for i in range(16))[2]
-        assert (win, hex(sl[win])) == (5, "0x56484f1ce06cd14a")
+        win = min((tot[i], aerr0[i], i) for i in range(16))[2]
+        assert (win, dev_win, hex(sl[win])) == (5, 5, "0x56484f1ce06cd14a")
 
 
 def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
@@ -360,10 +363,37 @@ def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
         smp = rng_pcm(trial, length, kind)
         s, sf, (eh, ew), totals = oracle.encode_slice(hist, w, smp)
         for generic in (0, 1):
-            tot, fst, sl, es = _gpu_slice(hist + w, smp, generic)
+            tot, aerr0, sl, es, dev_win = _gpu_slice(hist + w, smp, generic)
             assert tot == totals, (trial, generic)
-            win = min((tot[i], fst[i], i) for i in range(16))[2]
-            assert win == sf
+            win = min((tot[i], aerr0[i], i) for i in range(16))[2]
+            assert win == sf == dev_win
             shift = (20 - length) * 3
             assert sl[win] == (s << shift) & (2 ** 64 - 1)
             assert list(es[win]) == eh + ew
+
+
+def test_rank_ties_resolved_like_the_reference(gpu, oracle):
+    """Ties on the total rank must go to the candidate that is first in (first-sample rank, sf) order
+    (strict '<' at src/lib.rs:587, stable insertion sort at :536).  Tied slices are found by searching small
+    signals with the oracle (about 1 % of short low-amplitude slices tie); the device's own winner must be
+    the oracle's on every one of them."""
+    r = np.random.default_rng(1)
+    ties = first_rank_decides = 0
+    for trial in range(20000):
+        amp = int(r.integers(1, 60))
+        length = 20 if trial % 3 else int(r.integers(1, 6))
+        smp = r.integers(-amp, amp + 1, length).astype(np.int16)
+        st = [int(v) for v in r.integers(-3, 4, 4)] + [int(v) for v in r.integers(-300, 300, 4)]
+        s, sf, _, totals = oracle.encode_slice(st[:4], st[4:], smp)
+        tied = [i for i in range(16) if totals[i] == min(totals)]
+        if len(tied) < 2:
+            continue
+        ties += 1
+        tot, aerr0, sl, es, dev_win = _gpu_slice(st, smp, 0)
+        assert tot == totals
+        assert dev_win == sf, (list(smp), st, totals)
+        assert sf == min(tied, key=lambda i: (aerr0[i], i))
+        first_rank_decides += sf != min(tied)
+        if ties >= 120:
+            break
+    assert ties >= 100 and first_rank_decides >= 1
