@@ -121,51 +121,54 @@ struct StepConst {
 
 __device__ __forceinline__ void cand_step(int smp, const StepConst &k, Lms &l, int &s0, int &s1, int &s2, int &s3,
                                           unsigned long long &e, unsigned &pen_sum, unsigned &acc, int &err_out) {
-    int nw0, nw1, nw2, nw3, recon, ns3, err, t, u, sneg;
+    int nw0, nw1, nw2, nw3, recon, ns3, err, t, u, sneg, d;
+    // Order: a lone wave issues an instruction that depends on its predecessor ~0.5 cycle later than an
+    // independent one (tools/ubench), so the predict and penalty chains are interleaved and the off-path work
+    // (code packing, weight update, rank sum) is slotted between the dependent steps of the quantiser.
     asm("v_mul_lo_u32 v124, %[w0], %[h0]\n\t"
-        "v_mad_u64_u32 v[124:125], vcc, %[w1], %[h1], v[124:125]\n\t"
-        "v_mad_u64_u32 v[124:125], vcc, %[w2], %[h2], v[124:125]\n\t"
-        "v_mad_u64_u32 v[124:125], vcc, %[w3], %[h3], v[124:125]\n\t"
-        "v_ashrrev_i32 v124, 13, v124\n\t"                     // v124 = predicted
         "v_mul_lo_u32 v126, %[w0], %[w0]\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, %[w1], %[h1], v[124:125]\n\t"
         "v_mad_u64_u32 v[126:127], vcc, %[w1], %[w1], v[126:127]\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, %[w2], %[h2], v[124:125]\n\t"
         "v_mad_u64_u32 v[126:127], vcc, %[w2], %[w2], v[126:127]\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, %[w3], %[h3], v[124:125]\n\t"
         "v_mad_u64_u32 v[126:127], vcc, %[w3], %[w3], v[126:127]\n\t"
+        "v_ashrrev_i32 v124, 13, v124\n\t"                     // v124 = predicted
         "v_ashrrev_i32 v126, 18, v126\n\t"
-        "v_max_i32 v126, 0x8ff, v126\n\t"
-        "v_add_u32 v126, 0xfffff701, v126\n\t"                 // penalty = max(x - 0x8ff, 0)
-        "v_mad_i32_i24 %[pen], v126, v126, %[pen]\n\t"
         "v_sub_u32 %[t], %[smp], v124\n\t"                     // residual
+        "v_max_i32 v126, 0x8ff, v126\n\t"
         "v_mad_i32_i24 %[u], %[t], %[recip], %[rnd]\n\t"
+        "v_add_u32 v126, 0xfffff701, v126\n\t"                 // penalty = max(x - 0x8ff, 0)
         "v_med3_i32 %[t], %[t], -1, 1\n\t"                     // sgn(residual)
         "v_ashrrev_i32 %[u], 16, %[u]\n\t"                     // n
+        "v_mad_i32_i24 %[pen], v126, v126, %[pen]\n\t"
         "v_add_u32 %[t], %[u], %[t]\n\t"
         "v_med3_i32 %[u], %[u], -1, 1\n\t"                     // sgn(n)
         "v_sub_u32 %[u], %[t], %[u]\n\t"                       // scaled
-        "v_ashrrev_i32 %[sneg], 31, %[u]\n\t"
         "v_sub_u32 %[t], 0, %[u]\n\t"
+        "v_ashrrev_i32 %[sneg], 31, %[u]\n\t"
         "v_max_i32 %[t], %[u], %[t]\n\t"                       // |scaled|
         "v_min_i32 %[t], 7, %[t]\n\t"
         "v_and_b32 %[t], 6, %[t]\n\t"                          // 2*level
+        "v_mad_u32_u24 %[d], %[t], %[c101], %[selb]\n\t"
         "v_lshl_add_u32 %[acc], %[acc], 3, %[t]\n\t"
+        "v_perm_b32 %[d], %[dqhi], %[dqlo], %[d]\n\t"          // magnitude
         "v_sub_u32 %[acc], %[acc], %[sneg]\n\t"                // acc = acc<<3 | code
-        "v_mad_u32_u24 %[t], %[t], %[c101], %[selb]\n\t"
-        "v_perm_b32 %[t], %[dqhi], %[dqlo], %[t]\n\t"          // magnitude
-        "v_xor_b32 %[t], %[t], %[sneg]\n\t"
-        "v_sub_u32 %[t], %[t], %[sneg]\n\t"                    // dequantised
-        "v_add_u32 %[recon], %[t], v124\n\t"
+        "v_xor_b32 %[d], %[d], %[sneg]\n\t"
+        "v_sub_u32 %[d], %[d], %[sneg]\n\t"                    // dequantised
+        "v_add_u32 %[recon], %[d], v124\n\t"
+        "v_ashrrev_i32 %[d], 4, %[d]\n\t"                      // delta
         "v_med3_i32 %[recon], %[recon], %[lo], %[hi]\n\t"      // reconstructed
+        "v_mad_i32_i24 %[nw0], %[s0], %[d], %[w0]\n\t"
         "v_sub_u32 %[err], %[smp], %[recon]\n\t"
-        "v_mad_i64_i32 %[e], vcc, %[err], %[err], %[e]\n\t"    // rank += err^2
-        "v_ashrrev_i32 %[t], 4, %[t]\n\t"                      // delta
-        "v_mad_i32_i24 %[nw0], %[s0], %[t], %[w0]\n\t"
-        "v_mad_i32_i24 %[nw1], %[s1], %[t], %[w1]\n\t"
-        "v_mad_i32_i24 %[nw2], %[s2], %[t], %[w2]\n\t"
-        "v_mad_i32_i24 %[nw3], %[s3], %[t], %[w3]\n\t"
+        "v_mad_i32_i24 %[nw1], %[s1], %[d], %[w1]\n\t"
         "v_ashrrev_i32 %[ns3], 31, %[recon]\n\t"
+        "v_mad_i32_i24 %[nw2], %[s2], %[d], %[w2]\n\t"
+        "v_mad_i64_i32 %[e], vcc, %[err], %[err], %[e]\n\t"    // rank += err^2
+        "v_mad_i32_i24 %[nw3], %[s3], %[d], %[w3]\n\t"
         "v_or_b32 %[ns3], 1, %[ns3]"
         : [nw0] "=&v"(nw0), [nw1] "=&v"(nw1), [nw2] "=&v"(nw2), [nw3] "=&v"(nw3), [recon] "=&v"(recon),
-          [ns3] "=&v"(ns3), [err] "=&v"(err), [t] "=&v"(t), [u] "=&v"(u), [sneg] "=&v"(sneg), [e] "+v"(e),
+          [ns3] "=&v"(ns3), [err] "=&v"(err), [t] "=&v"(t), [u] "=&v"(u), [sneg] "=&v"(sneg), [d] "=&v"(d), [e] "+v"(e),
           [pen] "+v"(pen_sum), [acc] "+v"(acc)
         : [w0] "v"(l.w0), [w1] "v"(l.w1), [w2] "v"(l.w2), [w3] "v"(l.w3), [h0] "v"(l.h0), [h1] "v"(l.h1),
           [h2] "v"(l.h2), [h3] "v"(l.h3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [smp] "v"(smp),
