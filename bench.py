@@ -23,6 +23,19 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC profile (profiles/pmc_traffic.json: separate --pmc
+    passes, FETCH_SIZE doubled per the gfx950 correction).  PMC counters cannot be read from inside this process,
+    so the number is only reported for the exact workload it was collected on; otherwise null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    if (clips, channels, frames) != (1024, 2, 256):
+        return None
+    return d[kernel]["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(pcm_host: np.ndarray, channels: int, rate: int, budget_s: float):
     """The CPU oracle's ref_style encoder (the reference's algorithm incl. its rank-sorted early exits),
     one thread, on a bounded sample of the same clips.  kind = "port": the Rust reference cannot be built here."""
@@ -136,7 +149,8 @@ def main():
                    "samples_per_step": total_samples, "pcm_bytes_per_gpu": plan.pcm_bytes,
                    "encoded_bytes_per_gpu": plan.out_bytes, "parallelism": f"clips sharded over {world} GPU(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "qoa_encode_kernel",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("encode", n_clips, ch, args.frames), "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md"},
     }
@@ -169,7 +183,10 @@ def main():
         result["decode"] = {"value": dplan.samples / (d_ms * 1e-3), "unit": "samples/s", "kernel_ms_avg": d_ms,
                             "roofline": {"bound": "hbm", "achieved": d_bytes / (d_ms * 1e-3) / 1e9,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": d_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+                                         "frac": d_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "traffic": pmc_traffic("decode", n_clips, ch, args.frames),
+                                         "kernel": "qoa_decode_frames_kernel",
+                                         "algorithmic_bytes_per_launch": d_bytes},
                             "header_mismatches": dplan.mismatches(),
                             "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt())}
 
