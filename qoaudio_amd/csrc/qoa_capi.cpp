@@ -429,6 +429,7 @@ int Walker::walk(const uint8_t *data, size_t len, size_t *pos_io, std::vector<Fr
 struct DecTables {
     DevBuf frames[kMaxChannels + 1];
     unsigned n_frames[kMaxChannels + 1] = {0};
+    bool whole_pieces[kMaxChannels + 1] = {false};
     DevBuf chains;
     unsigned n_chains = 0;
     DevBuf mismatch;
@@ -445,10 +446,12 @@ struct DecTables {
                 generic.push_back(e);
             }
         }
-        hipError_t e = mismatch.reserve(sizeof(unsigned));
+        hipError_t e = mismatch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
         if (e == hipSuccess) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
         for (int n = 1; n <= kMaxChannels && e == hipSuccess; n++) {
             n_frames[n] = (unsigned)per[n].size();
+            whole_pieces[n] = true;
+            for (const DecChain &d : per[n]) if (((uint64_t)d.n_out * n * 2) % 16 != 0) whole_pieces[n] = false;
             if (per[n].empty()) continue;
             e = frames[n].reserve(per[n].size() * sizeof(DecChain));
             if (e == hipSuccess)
@@ -470,8 +473,8 @@ struct DecTables {
     }
     hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream) {
         for (int n = 1; n <= kMaxChannels; n++) {
-            hipError_t e = launch_decode_frames(n, d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
-                                                (unsigned *)mismatch.p, stream);
+            hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
+                                                (unsigned *)mismatch.p, (uint8_t *)mismatch.p + 64, stream);
             if (e != hipSuccess) return e;
         }
         return launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, (unsigned *)mismatch.p, stream);

@@ -16,8 +16,13 @@ hipError_t launch_decode(const uint8_t *d_in, int16_t *d_out, const DecChain *d_
                          unsigned *d_mismatches, hipStream_t stream);
 
 // K2 for 1..8 channels: one DecChain entry per FRAME (its `channel` field is ignored), LDS-transposed output
-hipError_t launch_decode_frames(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames,
-                                unsigned n_frames, unsigned *d_mismatches, hipStream_t stream);
+// d_scratch: kDecodeScratchBytes of device memory (sink for the stores of pieces beyond a frame's end)
+constexpr unsigned kDecodeScratchBytes = 1024;
+// whole_pieces: every frame's PCM byte count (n_out * nch * 2) is a multiple of 16 -> the variant without the
+// 2-byte tail path (no store under a branch, counted vmcnt waits)
+hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *d_in, int16_t *d_out,
+                                const DecChain *d_frames, unsigned n_frames, unsigned *d_mismatches,
+                                uint8_t *d_scratch, hipStream_t stream);
 
 // test hook: one slice, 16 candidates (device pointers; tot/fst/slice: 16 x u64, end_state: 16 x 8 x i32)
 hipError_t launch_debug_slice(const int32_t *d_state, const int32_t *d_samples, int len, int generic,

@@ -557,24 +557,27 @@ __global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restri
 }
 
 // K2: NCH in 1..8, one table entry per FRAME, 64/NCH frames per wavefront, LDS-transposed output.
-template <int NCH, int R>
-__global__ void __launch_bounds__(256) qoa_decode_frames_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
+// `scratch` points at kDecodeScratchBytes of device memory that absorbs the 16-byte stores of pieces that lie
+// beyond a frame's end: making every flush store unconditional keeps their count static, so hipcc can wait
+// for the prefetched slice with a counted vmcnt instead of draining the stores.
+template <int NCH, int R, int WPB, bool PARTIAL>
+__global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
                                                                 const DecChain *__restrict__ frames, unsigned n_frames,
-                                                                unsigned *__restrict__ mismatches) {
+                                                                unsigned *__restrict__ mismatches,
+                                                                uint8_t *__restrict__ scratch) {
     constexpr int FPW = 64 / NCH;               // frame groups per wavefront
     constexpr int GS = R * 20 * NCH * 2;        // bytes of one group's PCM image (R rows)
     constexpr int GSP = GS + 4;                 // odd dword stride: conflict-free 2-byte scatter across groups
     constexpr int PPG = GS / 16;                // 16-byte pieces per group image
+    constexpr int NP = (FPW * PPG + 63) / 64;   // pieces per lane per flush
     static_assert(GS % 16 == 0, "group image must be a whole number of 16-byte pieces");
-    struct GroupInfo { unsigned long long ptr; unsigned valid; unsigned pad; };
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[4][FPW * GSP + 12];
-    __shared__ __attribute__((aligned(16))) GroupInfo s_info[4][FPW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + 12];
     __shared__ uint2 s_mags[16];
     init_mag_table(s_mags);
 
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned g = lane / NCH, c = lane % NCH;
-    const unsigned frame_id = (blockIdx.x * 4u + wave) * FPW + g;
+    const unsigned frame_id = (blockIdx.x * (unsigned)WPB + wave) * FPW + g;
     const bool valid = (g < (unsigned)FPW) && frame_id < n_frames;
     DecChain fr;
     if (valid) fr = frames[frame_id];
@@ -609,50 +612,96 @@ __global__ void __launch_bounds__(256) qoa_decode_frames_kernel(const uint8_t *_
     }
     uint8_t *img = s_img[wave];
     const unsigned my_img = g * GSP + c * 2;
-    uint2 cur = *(const uint2 *)sp;
 
+    // Flush plan, fixed for the whole kernel: piece t of this lane is 16 bytes at byte k*16 of group gg's image.
+    // ptr[t] walks the group's output by GS bytes per flush; left[t] = bytes of the frame's output that remain
+    // at and after this piece (<= 0: nothing to store).
+    unsigned long long ptr[NP];
+    int left[NP];
+    unsigned src_off[NP];
+    {
+        const unsigned long long my_out = (unsigned long long)(out + fr.out_off);
+        const int my_bytes = (int)(fr.n_out * (unsigned)(NCH * 2));
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            const unsigned p = lane + 64u * t;
+            const unsigned gg = min(p / PPG, (unsigned)(FPW - 1)), k = p % PPG;
+            const int from = (int)((gg * NCH) << 2);
+            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)my_out);
+            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(my_out >> 32));
+            const int bytes = __builtin_amdgcn_ds_bpermute(from, my_bytes);
+            ptr[t] = ((((unsigned long long)hi) << 32) | lo) + k * 16;
+            left[t] = (p < (unsigned)(FPW * PPG)) ? bytes - (int)(k * 16) : 0;
+            src_off[t] = gg * GSP + k * 16;
+        }
+    }
+    uint8_t *const dummy = scratch + lane * 16;
+
+    // The slice of the NEXT row is loaded while the current row decodes, and is byte-swapped (i.e. waited for)
+    // at the END of the current row -- before the flush stores of a chunk are issued -- so that no vmcnt wait
+    // for a load can ever sit behind those stores.
+    unsigned hi, lo;
+    {
+        const uint2 first = *(const uint2 *)sp;
+        hi = bswap32(first.x);
+        lo = bswap32(first.y);
+    }
+    uint2 dq = s_mags[hi >> 28];
     for (unsigned row0 = 0; __builtin_amdgcn_ballot_w64(row0 < rows) != 0ull; row0 += R) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const unsigned row = row0 + r;
             const uint2 nxt = *(const uint2 *)(sp + (size_t)min(row + 1, rows_ld - 1) * (8 * NCH)); // prefetch
-            const unsigned hi = bswap32(cur.x), lo = bswap32(cur.y);
             const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
-            const uint2 dq = s_mags[hi >> 28];
 #pragma unroll
             for (int i = 0; i < 20; i++) {
                 int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
                 *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
             }
-            cur = nxt;
+            hi = bswap32(nxt.x);
+            lo = bswap32(nxt.y);
+            dq = s_mags[hi >> 28];
         }
-        // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step
-        if (c == 0 && g < (unsigned)FPW) {
-            unsigned done = row0 * 20u;
-            unsigned left = fr.n_out > done ? fr.n_out - done : 0u; // tail / truncated stream: src/lib.rs:320-328
-            GroupInfo gi;
-            gi.ptr = (unsigned long long)(out + fr.out_off + (size_t)done * NCH);
-            gi.valid = min(left, (unsigned)(R * 20)) * (NCH * 2);
-            gi.pad = 0;
-            s_info[wave][g] = gi;
+        // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step.
+        // All LDS reads first (one wait), then NP unconditional stores.
+        typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(2)));
+        typedef unsigned u32_alias __attribute__((may_alias));
+        asm volatile("" ::: "memory"); // the image was written as int16: keep the dword reads below behind those stores
+        u4_unaligned v[NP];
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            const u32_alias *src = (const u32_alias *)(img + src_off[t]);
+            v[t] = u4_unaligned{src[0], src[1], src[2], src[3]};
         }
-        for (unsigned p = lane; p < (unsigned)(FPW * PPG); p += 64) {
-            const unsigned gg = p / PPG, k = p % PPG;
-            const GroupInfo gi = s_info[wave][gg];
-            const unsigned off = k * 16;
-            if (off < gi.valid) {
-                const unsigned *src = (const unsigned *)(img + gg * GSP + off);
-                uint8_t *dst = (uint8_t *)gi.ptr + off;
-                if (off + 16 <= gi.valid) {
-                    typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(2)));
-                    u4_unaligned v = {src[0], src[1], src[2], src[3]};
-                    *(u4_unaligned *)dst = v;
-                } else {
-                    const unsigned n16 = (gi.valid - off) >> 1;
-                    for (unsigned q = 0; q < n16; q++) ((int16_t *)dst)[q] = ((const int16_t *)src)[q];
+        asm volatile("" ::: "memory");
+        bool any_partial = false;
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            // global address space spelled out: a generic pointer here becomes flat_store, which hipcc can only
+            // wait for with vmcnt(0) & lgkmcnt(0)
+            typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
+            const unsigned long long dst = left[t] >= 16 ? ptr[t] : (unsigned long long)dummy;
+// Non-temporal stores measured on MI355X (config-3 shapes): +13 % at 2 channels, +3 % at 4 and 8, but
+            // -8 % / -1.5 % at 1 / 3 channels (short odd-sized pieces) -> used for even channel counts only.
+            if (NCH % 2 == 0) __builtin_nontemporal_store(v[t], (gptr_t)dst);
+            else *(gptr_t)dst = v[t];
+            any_partial |= (left[t] > 0 && left[t] < 16);
+        }
+        // PARTIAL = false is launched when every frame's PCM is a whole number of 16-byte pieces (always true for
+        // full 5120-sample frames): with no store under a branch hipcc can count the stores and waits for the
+        // next prefetched slice with vmcnt(NP) instead of vmcnt(0), i.e. it never drains the write queue.
+        if (PARTIAL && __builtin_amdgcn_ballot_w64(any_partial) != 0ull) { // last piece of a short frame: 2-byte stores
+#pragma unroll
+            for (int t = 0; t < NP; t++) {
+                if (left[t] > 0 && left[t] < 16) {
+                    const unsigned n16 = (unsigned)left[t] >> 1;
+                    const int16_t *src16 = (const int16_t *)(img + src_off[t]);
+                    for (unsigned q = 0; q < n16; q++) ((int16_t *)ptr[t])[q] = src16[q];
                 }
             }
         }
+#pragma unroll
+        for (int t = 0; t < NP; t++) { ptr[t] += GS; left[t] -= GS; }
     }
 }
 
@@ -705,15 +754,16 @@ hipError_t launch_decode(const uint8_t *in, int16_t *out, const DecChain *chains
     return hipGetLastError();
 }
 
-template <int R>
+template <int R, int WPB, bool PARTIAL>
 static hipError_t launch_decode_frames_r(int nch, const uint8_t *in, int16_t *out, const DecChain *frames,
-                                         unsigned n_frames, unsigned *mismatches, hipStream_t stream) {
-    dim3 b(256);
+                                         unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
+    dim3 b(64 * WPB);
 #define QOA_LAUNCH(N)                                                                                              \
     case N: {                                                                                                      \
-        unsigned per_block = 4u * (64u / N);                                                                       \
+        unsigned per_block = (unsigned)WPB * (64u / N);                                                            \
         dim3 g((n_frames + per_block - 1) / per_block);                                                            \
-        hipLaunchKernelGGL((qoa_decode_frames_kernel<N, R>), g, b, 0, stream, in, out, frames, n_frames, mismatches); \
+        hipLaunchKernelGGL((qoa_decode_frames_kernel<N, R, WPB, PARTIAL>), g, b, 0, stream, in, out, frames, n_frames, \
+                           mismatches, scratch);                                                                   \
         break;                                                                                                     \
     }
     switch (nch) {
@@ -724,13 +774,11 @@ static hipError_t launch_decode_frames_r(int nch, const uint8_t *in, int16_t *ou
     return hipGetLastError();
 }
 
-hipError_t launch_decode_frames(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
-                                unsigned *mismatches, hipStream_t stream) {
+hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *in, int16_t *out, const DecChain *frames,
+                                unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
-    // rows per LDS flush: 4 measured faster than 2 on MI355X (2.65 vs 2.85 ms, config 3) despite 3 vs 7 blocks per CU
-    static const int rows_per_flush = [] { const char *e = getenv("QOA_DECODE_ROWS"); return e ? atoi(e) : 4; }();
-    if (rows_per_flush == 4) return launch_decode_frames_r<4>(nch, in, out, frames, n_frames, mismatches, stream);
-    return launch_decode_frames_r<2>(nch, in, out, frames, n_frames, mismatches, stream);
+    if (whole_pieces) return launch_decode_frames_r<4, 4, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
+    return launch_decode_frames_r<4, 4, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
 }
 
 } // namespace qoa
