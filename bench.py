@@ -103,6 +103,7 @@ def main():
     out = torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev)
     plan = batch.EncodePlan(clips)
     stream = torch.cuda.current_stream()
+    gather_dst = torch.empty((n_clips * world, per_enc), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
 
     def step(events=None):
         if events is not None:
@@ -113,7 +114,7 @@ def main():
             e1.record(stream)
             events.append((e0, e1))
         if world > 1:
-            return qdist.gather_encoded(out, n_clips * world, dst=0)
+            return qdist.gather_encoded(out, n_clips * world, dst=0, out=gather_dst)
         return out
 
     for _ in range(args.warmup):

@@ -140,6 +140,15 @@ int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint
  * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
 int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);
 
+/* ---- batch encode on HOST-resident buffers: time-sliced pipeline ----
+ * Semantically encode_all per clip (src/lib.rs:760-763) with h_pcm / h_out in host memory (pinned memory makes
+ * the copies asynchronous).  The batch is cut along TIME: frames [j*F, (j+1)*F) of all clips are one kernel
+ * launch (LMS state carried in device memory, as encode_frame does, src/lib.rs:414), overlapped with the
+ * host->device copy of the next time slice and the device->host copy of the previous one.  chunk_frames = F,
+ * 0 picks the default (16).  Synchronous: returns when h_out is complete. */
+int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
+                          uint32_t chunk_frames);
+
 /* ================================================================== decoder */
 
 /* FrameHeader, src/lib.rs:774-781 */

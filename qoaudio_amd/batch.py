@@ -159,6 +159,21 @@ def encode_batch(pcm: torch.Tensor, sample_rate: int, flags: int = PLAN_DEFAULT)
     return out
 
 
+def encode_batch_host(pcm: torch.Tensor, clips: Sequence[Tuple[int, int, QoaDesc]], out: torch.Tensor,
+                      chunk_frames: int = 0) -> None:
+    """Host-memory batch encode through the time-sliced pipeline (qoa_encode_batch_host).  pcm: int16 CPU tensor
+    (pinned for asynchronous copies), out: uint8 CPU tensor; offsets in `clips` index into them."""
+    if pcm.is_cuda or out.is_cuda:
+        raise ValueError("encode_batch_host takes host tensors; use EncodePlan for device tensors")
+    if pcm.dtype != torch.int16 or out.dtype != torch.uint8 or not pcm.is_contiguous() or not out.is_contiguous():
+        raise ValueError("pcm must be contiguous int16 and out contiguous uint8")
+    arr = _clips_array(clips)
+    rc = _lib.lib().qoa_encode_batch_host(arr, len(clips), C.c_void_p(pcm.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          chunk_frames)
+    if rc:
+        raise EncodeError(rc)
+
+
 def decode_batch(enc: torch.Tensor, desc: QoaDesc) -> torch.Tensor:
     """enc: uint8 device tensor [n_clips, encoded_size] as encode_batch wrote it -> int16 [n, samples, channels]."""
     n = enc.shape[0]

@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     int *tile = s_smp[wave_in_block][grp];
 
     const EncChain ch = chains[chain_id];
+    if (ch.samples == 0) return; // a clip that has no frames in this time slice (host pipeline): state untouched
     const int16_t *p = pcm + ch.pcm_off;
     const unsigned samples = ch.samples;
     const unsigned nslices = (samples + 19u) / 20u;

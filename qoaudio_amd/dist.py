@@ -41,9 +41,11 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local_rank
 
 
-def gather_encoded(local: torch.Tensor, n_total: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_encoded(local: torch.Tensor, n_total: int, dst: int = 0, group=None,
+                   out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Gather every rank's [n_local, per_enc] uint8 shard (block partition of n_total clips, see shard_range)
-    into [n_total, per_enc] on rank `dst`; other ranks return None."""
+    into [n_total, per_enc] on rank `dst`; other ranks return None.  `out` may be a preallocated destination
+    (rank dst only); with an even partition every peer's shard is received straight into its slice of it."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
@@ -52,19 +54,25 @@ def gather_encoded(local: torch.Tensor, n_total: int, dst: int = 0, group=None) 
     counts = [shard_range(n_total, r, world) for r in range(world)]
     assert local.shape[0] == counts[rank][1] - counts[rank][0], "shard does not match shard_range()"
     n_max = max(b - a for a, b in counts)
-    send = local
-    if local.shape[0] != n_max:  # uneven tail: pad to the common size, trimmed again on dst
+    even = all(b - a == n_max for a, b in counts)
+    send = local.contiguous()
+    if not even and local.shape[0] != n_max:  # uneven tail: pad to the common size, trimmed again on dst
         send = torch.zeros((n_max, per_enc), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
-    if rank == dst:
-        parts = [torch.empty((n_max, per_enc), dtype=local.dtype, device=local.device) for _ in range(world)]
-        dist.gather(send.contiguous(), gather_list=parts, dst=dst, group=group)
+    if rank != dst:
+        dist.gather(send, gather_list=None, dst=dst, group=group)
+        return None
+    if out is None:
         out = torch.empty((n_total, per_enc), dtype=local.dtype, device=local.device)
-        for r, (a, b) in enumerate(counts):
-            out[a:b] = parts[r][: b - a]
+    if even:
+        parts = [out[a:b] for a, b in counts]  # contiguous row blocks of `out`: no staging copy
+        dist.gather(send, gather_list=parts, dst=dst, group=group)
         return out
-    dist.gather(send.contiguous(), gather_list=None, dst=dst, group=group)
-    return None
+    parts = [torch.empty((n_max, per_enc), dtype=local.dtype, device=local.device) for _ in range(world)]
+    dist.gather(send, gather_list=parts, dst=dst, group=group)
+    for r, (a, b) in enumerate(counts):
+        out[a:b] = parts[r][: b - a]
+    return out
 
 
 def barrier_max_ms(elapsed_ms: float, device) -> float:

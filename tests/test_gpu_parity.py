@@ -397,3 +397,40 @@ def test_rank_ties_resolved_like_the_reference(gpu, oracle):
         if ties >= 120:
             break
     assert ties >= 100 and first_rank_decides >= 1
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pipeline_equals_encode_all(gpu, oracle, pinned):
+    """qoa_encode_batch_host (time-sliced pipeline, LMS state carried across slices in device memory): uniform
+    batch (2-D copies) and ragged mixed-channel batch (per-clip copies), several time slices each."""
+    from qoaudio_amd import batch
+    # uniform: 24 stereo clips of 7 frames + a tail, 3 frames per time slice
+    n, samples, ch = 24, 7 * 5120 + 1234, 2
+    desc = gpu.QoaDesc(ch, 32000, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n, desc)
+    pcm = torch.from_numpy(np.stack([rng_pcm(500 + i, samples * ch) for i in range(n)]))
+    out = torch.zeros(n * per_enc, dtype=torch.uint8)
+    if pinned:
+        pcm, out = pcm.pin_memory(), out.pin_memory()
+    batch.encode_batch_host(pcm, clips, out, chunk_frames=3)
+    for i in (0, 7, 23):
+        assert out[i * per_enc:(i + 1) * per_enc].numpy().tobytes() == \
+            oracle.encode_all(pcm[i].numpy().reshape(-1), ch, 32000, samples)
+    # ragged: different lengths and channel counts, 2 frames per slice; some clips end slices earlier than others
+    shapes = [(2, 5120 * 5 + 7), (1, 100), (3, 5120 * 2), (2, 5120 * 2 + 1), (8, 5120 * 3 + 19), (1, 5120 * 6), (2, 20)]
+    rclips, parts, po, oo = [], [], 0, 0
+    for i, (c, s) in enumerate(shapes):
+        x = rng_pcm(900 + i, s * c, "mix" if i % 2 else "white")
+        parts.append(x)
+        rclips.append((po, oo, gpu.QoaDesc(c, 44100, s)))
+        po += x.size
+        oo += gpu.encoded_size(c, s)
+    rp = torch.from_numpy(np.concatenate(parts))
+    ro = torch.zeros(oo, dtype=torch.uint8)
+    if pinned:
+        rp, ro = rp.pin_memory(), ro.pin_memory()
+    batch.encode_batch_host(rp, rclips, ro, chunk_frames=2)
+    host = ro.numpy()
+    for (p0, o0, d), x in zip(rclips, parts):
+        want = oracle.encode_all(x, d.channels, d.sample_rate, d.samples)
+        assert host[o0:o0 + len(want)].tobytes() == want, d

@@ -115,3 +115,27 @@ def test_cpp_mirror_runs_the_reference_suite(gpu, tmp_path):
     r = subprocess.run([str(exe), FIXTURE], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout + r.stderr
     assert r.stdout.count("ok   test_") == 10
+
+
+def test_wav_cli_round_trip(gpu, oracle, tmp_path):
+    """examples/encode.rs + examples/decode.rs equivalents: WAV -> QOA -> WAV."""
+    import wave
+    from qoaudio_amd import cli
+    from conftest import rng_pcm
+    x = rng_pcm(77, 3000 * 2)
+    src, mid, dst = str(tmp_path / "a.wav"), str(tmp_path / "a.qoa"), str(tmp_path / "b.wav")
+    with wave.open(src, "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(22050)
+        w.writeframes(x.astype("<i2").tobytes())
+    assert cli.main(["encode", src, mid]) == 0
+    assert open(mid, "rb").read() == oracle.encode_all(x, 2, 22050, 3000)
+    assert cli.main(["decode", mid, dst]) == 0
+    with wave.open(dst, "rb") as w:
+        assert (w.getnchannels(), w.getframerate(), w.getnframes()) == (2, 22050, 3000)
+        got = np.frombuffer(w.readframes(3000), dtype="<i2")
+    _, _, want = oracle.decode_all(open(mid, "rb").read())
+    assert np.array_equal(got, want)
+    assert cli.main(["info", mid]) == 0
+    assert cli.main(["decode", src, dst]) == 1  # a WAV is not a QOA file

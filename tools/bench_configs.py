@@ -81,4 +81,11 @@ for _ in range(2):
 out["config3_pcie_inclusive_serial"] = {"h2d_ms": (t1 - t0) * 1e3, "h2d_GBps": plan.pcm_bytes / (t1 - t0) / 1e9, "kernel_ms": (t2 - t1) * 1e3,
                                         "d2h_ms": (t3 - t2) * 1e3, "d2h_GBps": plan.out_bytes / (t3 - t2) / 1e9,
                                         "samples_per_s_end_to_end": plan.samples / (t3 - t0)}
+# the same from host memory through the time-sliced pipeline (qoa_encode_batch_host)
+host_out.zero_()
+for cf in (32, 16):
+    batch.encode_batch_host(host_pcm.view(-1), clips, host_out.view(-1), chunk_frames=cf)
+    t0 = time.perf_counter(); batch.encode_batch_host(host_pcm.view(-1), clips, host_out.view(-1), chunk_frames=cf); dt = time.perf_counter() - t0
+    out[f"config3_host_pipeline_chunk{cf}"] = {"wall_ms": dt * 1e3, "samples_per_s_end_to_end": plan.samples / dt,
+                                               "bytes_equal_device_path": bool(torch.equal(host_out, d_out.cpu()))}
 print(json.dumps(out, indent=1))
