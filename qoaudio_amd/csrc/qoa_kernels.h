@@ -9,7 +9,6 @@ namespace qoa {
 
 // flags bit0: force the generic (32-bit multiply / tail) path for every slice (debug / parity tests)
 //       bit1: start every chain from a fresh encoder's LMS state instead of loading d_lms
-//       bit2: never use the 40-instruction no-wrap step (debug / parity tests)
 hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out, const EncChain *d_chains,
                          unsigned n_chains, int32_t *d_lms, unsigned flags, unsigned lds_bytes, hipStream_t stream);
 

@@ -181,90 +181,22 @@ __device__ __forceinline__ void cand_step(int smp, const StepConst &k, Lms &l, i
     err_out = err;
 }
 
-// The same step WITHOUT the sgn(residual) / sgn(n) fix-up of qoa_div: 40 instructions instead of 42.
-// While res * recip + 2^15 does not wrap the i32 -- always for scalefactors >= 2, and for |res| < 32768 at
-// scalefactors 0 and 1 -- n is 0 or has the sign of the residual, so scaled = n + sgn(res) - sgn(n) differs
-// from n only by turning 0 into +-1: the level (min(|n|,7)&6) is the same and the sign of scaled is the sign of
-// the residual.  `chk` ORs (res + 32768) over the slice: any bit above 15 set means some step left that range
-// and the caller re-runs the slice with the exact step (rare: it takes a half-scale jump against the prediction).
-__device__ __forceinline__ void cand_step_nowrap(int smp, const StepConst &k, Lms &l, int &s0, int &s1, int &s2, int &s3,
-                                                 unsigned long long &e, unsigned &pen_sum, unsigned &acc, int &err_out,
-                                                 unsigned &chk) {
-    int nw0, nw1, nw2, nw3, recon, ns3, err, t, u, sneg, d;
-    asm("v_mul_lo_u32 v124, %[w0], %[h0]\n\t"
-        "v_mul_lo_u32 v126, %[w0], %[w0]\n\t"
-        "v_mad_u64_u32 v[124:125], vcc, %[w1], %[h1], v[124:125]\n\t"
-        "v_mad_u64_u32 v[126:127], vcc, %[w1], %[w1], v[126:127]\n\t"
-        "v_mad_u64_u32 v[124:125], vcc, %[w2], %[h2], v[124:125]\n\t"
-        "v_mad_u64_u32 v[126:127], vcc, %[w2], %[w2], v[126:127]\n\t"
-        "v_mad_u64_u32 v[124:125], vcc, %[w3], %[h3], v[124:125]\n\t"
-        "v_mad_u64_u32 v[126:127], vcc, %[w3], %[w3], v[126:127]\n\t"
-        "v_ashrrev_i32 v124, 13, v124\n\t"                     // v124 = predicted
-        "v_ashrrev_i32 v126, 18, v126\n\t"
-        "v_sub_u32 %[t], %[smp], v124\n\t"                     // residual
-        "v_max_i32 v126, 0x8ff, v126\n\t"
-        "v_mad_i32_i24 %[u], %[t], %[recip], %[rnd]\n\t"
-        "v_add_u32 v126, 0xfffff701, v126\n\t"                 // penalty = max(x - 0x8ff, 0)
-        "v_ashrrev_i32 %[sneg], 31, %[t]\n\t"                  // sign of the residual = sign of scaled
-        "v_add_u32 %[t], 0x8000, %[t]\n\t"
-        "v_ashrrev_i32 %[u], 16, %[u]\n\t"                     // n
-        "v_or_b32 %[chk], %[chk], %[t]\n\t"                    // range check of the residual
-        "v_mad_i32_i24 %[pen], v126, v126, %[pen]\n\t"
-        "v_sub_u32 %[t], 0, %[u]\n\t"
-        "v_max_i32 %[t], %[u], %[t]\n\t"                       // |n|
-        "v_min_i32 %[t], 7, %[t]\n\t"
-        "v_and_b32 %[t], 6, %[t]\n\t"                          // 2*level
-        "v_mad_u32_u24 %[d], %[t], %[c101], %[selb]\n\t"
-        "v_lshl_add_u32 %[acc], %[acc], 3, %[t]\n\t"
-        "v_perm_b32 %[d], %[dqhi], %[dqlo], %[d]\n\t"          // magnitude
-        "v_sub_u32 %[acc], %[acc], %[sneg]\n\t"                // acc = acc<<3 | code
-        "v_xor_b32 %[d], %[d], %[sneg]\n\t"
-        "v_sub_u32 %[d], %[d], %[sneg]\n\t"                    // dequantised
-        "v_add_u32 %[recon], %[d], v124\n\t"
-        "v_ashrrev_i32 %[d], 4, %[d]\n\t"                      // delta
-        "v_med3_i32 %[recon], %[recon], %[lo], %[hi]\n\t"      // reconstructed
-        "v_mad_i32_i24 %[nw0], %[s0], %[d], %[w0]\n\t"
-        "v_sub_u32 %[err], %[smp], %[recon]\n\t"
-        "v_mad_i32_i24 %[nw1], %[s1], %[d], %[w1]\n\t"
-        "v_ashrrev_i32 %[ns3], 31, %[recon]\n\t"
-        "v_mad_i32_i24 %[nw2], %[s2], %[d], %[w2]\n\t"
-        "v_mad_i64_i32 %[e], vcc, %[err], %[err], %[e]\n\t"    // rank += err^2
-        "v_mad_i32_i24 %[nw3], %[s3], %[d], %[w3]\n\t"
-        "v_or_b32 %[ns3], 1, %[ns3]"
-        : [nw0] "=&v"(nw0), [nw1] "=&v"(nw1), [nw2] "=&v"(nw2), [nw3] "=&v"(nw3), [recon] "=&v"(recon),
-          [ns3] "=&v"(ns3), [err] "=&v"(err), [t] "=&v"(t), [u] "=&v"(u), [sneg] "=&v"(sneg), [d] "=&v"(d), [e] "+v"(e),
-          [pen] "+v"(pen_sum), [acc] "+v"(acc), [chk] "+v"(chk)
-        : [w0] "v"(l.w0), [w1] "v"(l.w1), [w2] "v"(l.w2), [w3] "v"(l.w3), [h0] "v"(l.h0), [h1] "v"(l.h1),
-          [h2] "v"(l.h2), [h3] "v"(l.h3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [smp] "v"(smp),
-          [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi),
-          [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768)
-        : "vcc", "v124", "v125", "v126", "v127");
-    l.w0 = nw0; l.w1 = nw1; l.w2 = nw2; l.w3 = nw3;
-    l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
-    s0 = s1; s1 = s2; s2 = s3; s3 = ns3;
-    err_out = err;
-}
-
 __device__ __forceinline__ void sign_mults(const Lms &l, int &s0, int &s1, int &s2, int &s3) {
     s0 = (l.h0 >> 31) | 1; s1 = (l.h1 >> 31) | 1; s2 = (l.h2 >> 31) | 1; s3 = (l.h3 >> 31) | 1;
 }
 
-// A full 20-sample slice, fully unrolled (the history shift is register renaming).  EXACT = false uses the
-// 40-instruction step and returns true if some residual left the range in which that step is exact at
-// scalefactors 0/1 (only those two lanes can be wrong; the caller then re-runs the slice with EXACT = true).
-template <bool EXACT>
-__device__ __forceinline__ bool run_slice_full(const int (&smp)[20], int sf, const StepConst &k, const Lms &entry,
+// A full 20-sample slice, fully unrolled (the history shift is register renaming).
+__device__ __forceinline__ void run_slice_full(const int (&smp)[20], int sf, const StepConst &k, const Lms &entry,
                                                CandResult &r) {
     Lms l = entry;
     int s0, s1, s2, s3;
     sign_mults(l, s0, s1, s2, s3);
     unsigned long long e = 0;
-    unsigned pen = 0, acc_a = 0, acc_b = 0, chk = 0;
+    unsigned pen = 0, acc_a = 0, acc_b = 0;
 #pragma unroll
     for (int i = 0; i < 20; i++) {
         int err;
-        if (EXACT) cand_step(smp[i], k, l, s0, s1, s2, s3, e, pen, i < 10 ? acc_a : acc_b, err);
-        else cand_step_nowrap(smp[i], k, l, s0, s1, s2, s3, e, pen, i < 10 ? acc_a : acc_b, err, chk);
+        cand_step(smp[i], k, l, s0, s1, s2, s3, e, pen, i < 10 ? acc_a : acc_b, err);
         if (i == 0) r.aerr0 = uabs(err);
     }
     r.lms = l;
@@ -273,7 +205,6 @@ __device__ __forceinline__ bool run_slice_full(const int (&smp)[20], int sf, con
     // slice = sf<<60 | codes 0..9 <<30 | codes 10..19   (src/lib.rs:549,560,584)
     r.s_hi = ((unsigned)sf << 28) | (acc_a >> 2);
     r.s_lo = (acc_a << 30) | acc_b;
-    return !EXACT && sf < 2 && (chk >> 16) != 0;
 }
 
 // Any slice length 1..20 (the last slice of a clip).  Rolled loop; the sample window is shifted through
@@ -392,8 +323,6 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     kc.selbase = 0x0c0c0100u;
     kc.hi = 32767;
     const bool force_tail_path = (flags & 1u) != 0;
-    const bool exact_only = (flags & 4u) != 0; // debug: never use the 40-instruction step
-    unsigned exact_left = 0;                   // wave-uniform: slices still to run on the exact step
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -463,19 +392,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             const bool full = (len == 20) && !force_tail_path;
 
             CandResult r;
-            if (__builtin_amdgcn_ballot_w64(!full) != 0ull) {
-                run_slice_tail(smp, len, sf, kc, st, r);
-            } else if (exact_left != 0 || exact_only) {
-                run_slice_full<true>(smp, sf, kc, st, r);
-                exact_left -= (exact_left != 0);
+            if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
+                run_slice_full(smp, sf, kc, st, r);
             } else {
-                const bool redo = run_slice_full<false>(smp, sf, kc, st, r);
-                if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                    // some residual left +-32768 at scalefactor 0/1: the 40-instruction step is not exact there.
-                    // Re-run with the exact step and stay on it for a while (loud passages come in runs).
-                    run_slice_full<true>(smp, sf, kc, st, r);
-                    exact_left = 64;
-                }
+                run_slice_tail(smp, len, sf, kc, st, r);
             }
             const unsigned win = pick_winner(r, sf);
             const int src_lane = (int)((row_base | win) << 2);
@@ -533,11 +453,8 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 #pragma unroll
     for (int i = 0; i < 20; i++) smp[i] = samples[i];
     CandResult r;
-    // generic: 0 = production order (40-instruction step, exact redo if flagged), 1 = rolled tail path,
-    //          2 = exact 42-instruction step
-    if (generic == 1 || len != 20) run_slice_tail(smp, len, sf, kc, st, r);
-    else if (generic == 2) run_slice_full<true>(smp, sf, kc, st, r);
-    else if (__builtin_amdgcn_ballot_w64(run_slice_full<false>(smp, sf, kc, st, r)) != 0ull) run_slice_full<true>(smp, sf, kc, st, r);
+    if (generic || len != 20) run_slice_tail(smp, len, sf, kc, st, r);
+    else run_slice_full(smp, sf, kc, st, r);
     tot[sf] = r.e + r.pen;
     fst[sf] = ((unsigned long long)pick_winner(r, sf) << 32) | r.aerr0; // [63:32] winner of the row, [31:0] |err0|
     slice[sf] = ((unsigned long long)r.s_hi << 32) | r.s_lo;
