@@ -92,7 +92,7 @@ static inline uint32_t be32(const uint8_t *p) {
 }
 static inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
 
-// Chains-per-wavefront heuristic.  Measured on MI355X (profiles/r01_first_contact.txt): the kernel is
+// Chains-per-wavefront heuristic.  Measured on MI355X (profiles/r01a_kernel_stats.md): the kernel is
 // integer-VALU-issue bound and a gfx950 SIMD issues these integer ops at one wave-instruction per
 // ~4 cycles whether one or two wavefronts are resident, so throughput = 1 / (wave-instructions per
 // SIMD).  Packing 4 chains into each wavefront (all 64 lanes busy) is therefore never slower than
@@ -130,7 +130,6 @@ struct EncGroup {
     int nch = 0;
     int cpw = 1;
     unsigned n = 0;
-    unsigned lds = 0;
     DevBuf chains;
     DevBuf lms;
 };
@@ -209,13 +208,13 @@ extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_
     return QOA_OK;
 }
 
-// kernel flags: bit0 force generic path, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352)
+// kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352)
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u);
     for (auto *g : plan->groups) {
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
-                              kflags, g->lds, (hipStream_t)stream),
+                              kflags, (hipStream_t)stream),
                 QOA_ENCODE_IO_ERROR);
     }
     return QOA_OK;
@@ -295,11 +294,7 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
 
     // chains are ordered by channel count (one launch per count), the order is the same in every time slice so
     // that chain ids -- and with them the carried LMS states -- are stable
-    std::vector<size_t> order;
     unsigned group_begin[kMaxChannels + 2] = {0};
-    for (int nch = 1; nch <= kMaxChannels; nch++) {
-        group_begin[nch] = 0;
-    }
     std::vector<size_t> by_nch[kMaxChannels + 1];
     for (size_t i = 0; i < n_clips; i++) by_nch[clips[i].desc.channels].push_back(i);
 
@@ -351,7 +346,7 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
                 if (!n) continue;
                 HIP_TRY(launch_encode(pick_cpw(n, 0), nch, (const int16_t *)P.pcm[b].p, (uint8_t *)P.enc[b].p,
                                       (const EncChain *)P.chains[b].p + group_begin[nch], n,
-                                      (int32_t *)P.lms.p + (size_t)group_begin[nch] * 8, j == 0 ? 2u : 0u, 0u, P.s_k),
+                                      (int32_t *)P.lms.p + (size_t)group_begin[nch] * 8, j == 0 ? 2u : 0u, P.s_k),
                         QOA_ENCODE_IO_ERROR);
             }
             HIP_TRY(hipEventRecord(P.k_done[b], P.s_k), QOA_ENCODE_IO_ERROR);
@@ -464,7 +459,7 @@ static int encoder_run(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint3
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(enc->pcm.p, pcm, n_i16 * 2, hipMemcpyHostToDevice, enc->stream), QOA_ENCODE_IO_ERROR);
     HIP_TRY(launch_encode(1, enc->desc.channels, (const int16_t *)enc->pcm.p, (uint8_t *)enc->out.p,
-                          (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u, 0u,
+                          (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u,
                           enc->stream),
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(out, enc->out.p, out_bytes, hipMemcpyDeviceToHost, enc->stream), QOA_ENCODE_IO_ERROR);

@@ -7,10 +7,10 @@
 
 namespace qoa {
 
-// flags bit0: force the generic (32-bit multiply / tail) path for every slice (debug / parity tests)
+// flags bit0: run every slice through the rolled tail path (debug / parity tests)
 //       bit1: start every chain from a fresh encoder's LMS state instead of loading d_lms
 hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out, const EncChain *d_chains,
-                         unsigned n_chains, int32_t *d_lms, unsigned flags, unsigned lds_bytes, hipStream_t stream);
+                         unsigned n_chains, int32_t *d_lms, unsigned flags, hipStream_t stream);
 
 hipError_t launch_decode(const uint8_t *d_in, int16_t *d_out, const DecChain *d_chains, unsigned n_chains,
                          unsigned *d_mismatches, hipStream_t stream);

@@ -15,16 +15,12 @@
 // quantise/dequantise "tables" are two packed VGPRs read with v_perm_b32 -- an LDS lookup would put
 // ~64 cycles of latency on the serial path 20x per slice).  The winner is the lexicographic minimum
 // of (total rank, first-sample rank, scalefactor) -- the closed form of the reference's rank-sorted
-// order with its two early exits -- found with three 32-bit row_ror DPP min-reductions, and its end
+// order with its two early exits -- found with two 32-bit row_ror DPP min-reductions, and its end
 // state is handed to all 16 lanes with ds_bpermute.
 //
-// All arithmetic is 32-bit wrapping integer exactly as in the reference.  The fast path uses the
-// full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24), whose low 32 result bits equal the
-// wrapping i32 product whenever both operands fit in 24 signed bits; history (i16), residual
-// (|r| < 2^19), reciprocal (<= 2^16), error (17 bits) and penalty always do, weights do while
-// max|w| < 2^23 - 20*896 at slice entry (each step moves a weight by at most 14336>>4 = 896).  A
-// wave-uniform guard sends any other slice -- and the short tail slice of a clip -- through the
-// generic path with full 32-bit multiplies.
+// All arithmetic is 32-bit wrapping integer exactly as in the reference.  The kernel is bound by
+// VALU instruction ISSUE (one wave per SIMD, ~4 cycles per instruction whatever it is), so the
+// candidate step is one hand-written 42-instruction block (cand_step); see DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -40,15 +36,10 @@ __constant__ int c_mags[16][4] = QOA_DEQUANT_MAGS;
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-// 24-bit multiplies as single instructions with EXACT wrapping semantics: the low 32 bits of
-// sext24(a) * sext24(b) (+ c).  Not HIP's __mul24: that is `mul nsw` in the device library, i.e. signed
+// 24-bit multiply-add as a single instruction with EXACT wrapping semantics: the low 32 bits of
+// sext24(a) * sext24(b) + c.  Not HIP's __mul24: that is `mul nsw` in the device library, i.e. signed
 // overflow is undefined, and hipcc then narrows a u64 rank sum to 32 bits (caught by the parity tests:
 // err^2 reaches 2^32).  Inline asm keeps the instruction and drops the assumption.
-__device__ __forceinline__ int mul24(int a, int b) {
-    int r;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 __device__ __forceinline__ int mad24(int a, int b, int c) {
     int r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -58,13 +49,6 @@ __device__ __forceinline__ int mul32(int a, int b) { return (int)((unsigned)a * 
 // clamp(v, lo, hi); the backend folds min(max()) with constant bounds into one v_med3_i32
 __device__ __forceinline__ int med3(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ unsigned uabs(int v) { unsigned s = (unsigned)(v >> 31); return ((unsigned)v ^ s) - s; }
-__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
-// sgn(v) = clamp(v,-1,1) in ONE instruction (hipcc turns the C form into 2 compares + 2 selects)
-__device__ __forceinline__ int sgn(int v) {
-    int r;
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(v));
-    return r;
-}
 
 struct Lms {
     int h0, h1, h2, h3; // history, oldest first (src/lib.rs:72)
@@ -77,12 +61,6 @@ struct Lms {
 __device__ __forceinline__ unsigned long long mad32(int a, int b, unsigned long long acc) {
     unsigned long long r;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
-    return r;
-}
-// acc(u64) += (i64)a * a : the rank sum of squared errors in one instruction
-__device__ __forceinline__ unsigned long long mad_sq64(int a, unsigned long long acc) {
-    unsigned long long r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(a), "v"(acc) : "vcc");
     return r;
 }
 
@@ -711,14 +689,14 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 // ------------------------------------------------------------------------------------------------
 template <int CPW>
 static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
-                                    int32_t *lms, unsigned flags, unsigned lds_bytes, hipStream_t stream) {
+                                    int32_t *lms, unsigned flags, hipStream_t stream) {
     constexpr unsigned kWavesPerBlock = 4;
     unsigned waves = (n + CPW - 1) / CPW;
     unsigned blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     dim3 g(blocks), b(64 * kWavesPerBlock);
 #define QOA_LAUNCH(N)                                                                                              \
     case N:                                                                                                        \
-        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N>), g, b, lds_bytes, stream, pcm, out, chains, n, lms, flags); \
+        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N>), g, b, 0, stream, pcm, out, chains, n, lms, flags); \
         break;
     switch (nch) {
         QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
@@ -729,12 +707,12 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
 }
 
 hipError_t launch_encode(int cpw, int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
-                         int32_t *lms, unsigned flags, unsigned lds_bytes, hipStream_t stream) {
+                         int32_t *lms, unsigned flags, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     switch (cpw) {
-    case 1: return launch_encode_nch<1>(nch, pcm, out, chains, n, lms, flags, lds_bytes, stream);
-    case 2: return launch_encode_nch<2>(nch, pcm, out, chains, n, lms, flags, lds_bytes, stream);
-    case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, lds_bytes, stream);
+    case 1: return launch_encode_nch<1>(nch, pcm, out, chains, n, lms, flags, stream);
+    case 2: return launch_encode_nch<2>(nch, pcm, out, chains, n, lms, flags, stream);
+    case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, stream);
     default: return hipErrorInvalidValue;
     }
 }
