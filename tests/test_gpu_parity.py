@@ -434,3 +434,99 @@ def test_host_pipeline_equals_encode_all(gpu, oracle, pinned):
     for (p0, o0, d), x in zip(rclips, parts):
         want = oracle.encode_all(x, d.channels, d.sample_rate, d.samples)
         assert host[o0:o0 + len(want)].tobytes() == want, d
+
+
+def _crafted_stream(rng, frames, samples_field=0):
+    """Hand-built QOA bytes: frames = [(channels, rate, nspc, rows_present)], random LMS and slices.  The
+    encoder cannot produce >8 channels or frames whose sample count disagrees with their slice count, but the
+    reference decoder accepts both (src/lib.rs:227-244 validates only frame_size; :320-328 drives the reader)."""
+    out = bytearray(b"qoaf" + int(samples_field).to_bytes(4, "big"))
+    for ch, rate, nspc, rows in frames:
+        fsize = 8 + 16 * ch + 8 * min(rows, 256) * ch
+        out += bytes([ch]) + rate.to_bytes(3, "big") + nspc.to_bytes(2, "big") + (fsize & 0xffff).to_bytes(2, "big")
+        out += rng.integers(0, 256, 16 * ch, dtype=np.uint8).tobytes()
+        out += rng.integers(0, 256, 8 * rows * ch, dtype=np.uint8).tobytes()
+    return bytes(out)
+
+
+def _same_items(gpu, oracle, data):
+    ref = oracle.OracleDecoder(data)
+    dec = gpu.QoaDecoder(data)
+    n = 0
+    while True:
+        want = ref.next()
+        try:
+            got = dec.next()
+        except gpu.DecodeError as e:
+            got = ("Err", e.kind)
+        if want is None:
+            assert got is None
+            return n
+        if want[0] == "Sample":
+            assert got == gpu.Sample(want[1]), n
+        elif want[0] == "FrameHeader":
+            assert got == gpu.FrameHeader(*want[1])
+        else:
+            assert got == want
+            return n
+        n += 1
+
+
+def test_decoder_more_than_eight_channels(gpu, oracle):
+    """Up to 255 channels are legal for the decoder (u8 in the frame header); they take the generic kernel."""
+    r = np.random.default_rng(21)
+    for ch, rows in ((9, 3), (16, 5), (31, 2), (255, 1)):
+        nspc = rows * 20 - 7
+        data = _crafted_stream(r, [(ch, 44100, nspc, rows), (ch, 44100, 20, 1)], samples_field=nspc + 20)
+        n = _same_items(gpu, oracle, data)
+        assert n == 2 + (nspc + 20) * ch
+        d = gpu.decode_all(data)
+        _, _, want = oracle.decode_all(data)
+        assert d.num_channels == ch and np.array_equal(d.samples, want)
+
+
+def test_decoder_frame_longer_than_its_slices(gpu, oracle):
+    """num_samples_per_channel drives the reader, not frame_size (src/lib.rs:320-328): a frame may claim up to
+    65535 samples (3277 slice rows) and the decoder keeps reading slices from whatever follows."""
+    r = np.random.default_rng(22)
+    # 1 channel, claims 65535 samples, header says 256 slices, stream really holds 3277 rows
+    data = _crafted_stream(r, [(1, 8000, 65535, 3277)], samples_field=65535)
+    assert _same_items(gpu, oracle, data) == 1 + 65535
+    # 2 channels, claims 5000 samples but only 100 rows present -> 100 full rows, then IoError
+    data = _crafted_stream(r, [(2, 8000, 5000, 100)], samples_field=5000)
+    assert _same_items(gpu, oracle, data) == 1 + 100 * 20 * 2
+    # streaming mode (samples = 0), frames of different channel counts and odd lengths back to back
+    data = _crafted_stream(r, [(3, 8000, 41, 3), (1, 48000, 1, 1), (8, 22050, 5120, 256), (2, 8000, 39, 2)])
+    assert _same_items(gpu, oracle, data) == 1 + 4 + 41 * 3 + 1 + 5120 * 8 + 39 * 2
+    # extreme LMS weights in the header (all 0x8000 / 0x7fff) and all-ones slices
+    hostile = bytearray(_crafted_stream(r, [(2, 44100, 5120, 256)], samples_field=5120))
+    hostile[16:48] = bytes([0x80, 0x00, 0x7f, 0xff] * 8)
+    hostile[48:] = b"\xff" * (len(hostile) - 48)
+    assert _same_items(gpu, oracle, bytes(hostile)) == 1 + 5120 * 2
+
+
+def test_hypothesis_encode_decode_parity(gpu, oracle):
+    """Property test (hypothesis): arbitrary small int16 signals, 1-8 channels: GPU bytes == oracle bytes and
+    GPU decode == oracle decode (the reference's fuzz target, with parity on top)."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.integers(1, 8), st.integers(1, 130), st.integers(0, 2 ** 32 - 1),
+           st.sampled_from(["white", "mix", "loud", "square", "silence"]), st.integers(1, 2 ** 24 - 1))
+    def check(channels, n, seed, kind, rate):
+        x = rng_pcm(seed, n * channels, kind)
+        enc = gpu.encode_all(x, gpu.QoaDesc(channels, rate, n))
+        assert enc == oracle.encode_all(x, channels, rate, n)
+        d = gpu.decode_all(enc)
+        _, _, want = oracle.decode_all(enc)
+        assert (d.num_channels, d.sample_rate) == (channels, rate) and np.array_equal(d.samples, want)
+
+    check()
+
+
+def test_sample_rate_above_24_bits_overlaps_the_channel_byte(gpu, oracle):
+    """The encoder ORs the unmasked u32 rate into the frame header (src/lib.rs:448-449): rates >= 2^24 spill
+    into the channel byte.  Reproduced bit for bit; such a stream then fails to decode in the reference too."""
+    x = rng_pcm(9, 300)
+    for rate in (2 ** 24, 2 ** 24 + 44100, 2 ** 32 - 1):
+        assert gpu.encode_all(x, gpu.QoaDesc(1, rate, 300)) == oracle.encode_all(x, 1, rate, 300)
