@@ -100,37 +100,53 @@ def main():
     clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
     # synthetic PCM generated once, resident in HBM before anything is timed
     pcm = synth.make_clips(n_clips, samples, ch, args.rate, device=dev, first_index=rank * n_clips)
-    out = torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev)
+    # two output buffers: for N > 1 the gather of step i runs on the communication stream while step i+1 encodes
+    outs = [torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    out = outs[0]
     plan = batch.EncodePlan(clips)
     stream = torch.cuda.current_stream()
-    gather_dst = torch.empty((n_clips * world, per_enc), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    gather_dst = [torch.empty((n_clips * world, per_enc), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0)
+                  else None for _ in outs]
+    pending = [None] * len(outs)
 
-    def step(events=None):
+    def step(i, events=None):
+        b = i % len(outs)
+        if pending[b] is not None:  # the gather that last read outs[b] must be done before it is overwritten
+            pending[b].wait()
+            pending[b] = None
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        plan.run(pcm, out, stream)
+        plan.run(pcm, outs[b], stream)
         if events is not None:
             e1.record(stream)
             events.append((e0, e1))
         if world > 1:
-            return qdist.gather_encoded(out, n_clips * world, dst=0, out=gather_dst)
-        return out
+            pending[b], _ = qdist.gather_encoded_async(outs[b], n_clips * world, dst=0, out=gather_dst[b])
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for b in range(len(outs)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered = step(events)
+    for i in range(args.steps):
+        step(i, events)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed_ms = (time.perf_counter() - t0) * 1e3
     elapsed_ms = qdist.barrier_max_ms(elapsed_ms, dev)
+    gathered = gather_dst[(args.steps - 1) % len(outs)] if args.steps else None
     kernel_ms = [a.elapsed_time(b) for a, b in events]
 
     total_samples = plan.samples * world

@@ -41,6 +41,24 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local_rank
 
 
+def gather_encoded_async(local: torch.Tensor, n_total: int, dst: int = 0, group=None,
+                         out: Optional[torch.Tensor] = None):
+    """Even-partition gather that returns (work, out): the collective is enqueued (async_op=True) and the caller
+    waits on `work` before it reuses `local` or reads `out`.  Lets step i's gather run on the communication
+    stream while step i+1 encodes into a second output buffer (bench.py, N > 1)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [shard_range(n_total, r, world) for r in range(world)]
+    assert all(b - a == local.shape[0] for a, b in counts), "gather_encoded_async needs an even partition"
+    send = local if local.is_contiguous() else local.contiguous()
+    if rank != dst:
+        return dist.gather(send, gather_list=None, dst=dst, group=group, async_op=True), None
+    if out is None:
+        out = torch.empty((n_total, local.shape[1]), dtype=local.dtype, device=local.device)
+    parts = [out[a:b] for a, b in counts]
+    return dist.gather(send, gather_list=parts, dst=dst, group=group, async_op=True), out
+
+
 def gather_encoded(local: torch.Tensor, n_total: int, dst: int = 0, group=None,
                    out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Gather every rank's [n_local, per_enc] uint8 shard (block partition of n_total clips, see shard_range)

@@ -41,6 +41,14 @@ def _worker(rank, world, port, n_clips, samples, channels, q):
         x = rng_pcm(1000 + i, samples * channels)
         local[i - a] = torch.frombuffer(bytearray(O.encode_all(x, channels, 44100, samples)), dtype=torch.uint8)
     out = qdist.gather_encoded(local, n_clips, dst=0)
+    if n_clips % world == 0:  # the double-buffered asynchronous form bench.py uses for N > 1
+        bufs = [local.clone(), local.clone()]
+        dsts = [torch.zeros((n_clips, per_enc), dtype=torch.uint8) if rank == 0 else None for _ in bufs]
+        works = [qdist.gather_encoded_async(bufs[b], n_clips, dst=0, out=dsts[b])[0] for b in range(2)]
+        for wk in works:
+            wk.wait()
+        if rank == 0:
+            assert torch.equal(dsts[0], out) and torch.equal(dsts[1], out)
     ms = qdist.barrier_max_ms(float(rank + 1), torch.device("cpu"))
     if rank == 0:
         q.put((out.numpy().copy(), ms))
