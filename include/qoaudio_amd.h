@@ -242,7 +242,7 @@ int qoa_decode_plan_bytes(const qoa_decode_plan *plan, uint64_t *in_bytes, uint6
                           uint64_t *samples_i16);
 /* Enqueue the decode on `stream`.  d_in / d_out are DEVICE pointers.  Asynchronous. */
 int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream);
-/* After synchronising: number of frames whose header on the device disagreed with the plan
+/* After synchronising: number of frames whose header on the device disagreed with the plan in the LAST run
  * (from_clips plans only; 0 for a well-formed batch). */
 int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count);
 

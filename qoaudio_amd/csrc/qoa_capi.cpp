@@ -647,6 +647,8 @@ struct DecTables {
         return true;
     }
     hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream) {
+        hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream); // the count is per run
+        if (e0 != hipSuccess) return e0;
         for (int n = 1; n <= kMaxChannels; n++) {
             hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
                                                 (unsigned *)mismatch.p, (uint8_t *)mismatch.p + 64, stream);
