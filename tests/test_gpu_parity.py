@@ -530,3 +530,62 @@ def test_sample_rate_above_24_bits_overlaps_the_channel_byte(gpu, oracle):
     x = rng_pcm(9, 300)
     for rate in (2 ** 24, 2 ** 24 + 44100, 2 ** 32 - 1):
         assert gpu.encode_all(x, gpu.QoaDesc(1, rate, 300)) == oracle.encode_all(x, 1, rate, 300)
+
+
+def test_encoder_state_carries_across_calls_like_the_reference(gpu, oracle):
+    """QoaEncoder keeps its LMS state in `self` (src/lib.rs:89): a second encode() on the same object, or an
+    encode() after encode_frame() calls, continues from the carried state.  Same on the device handle."""
+    n, ch = 5120 + 300, 2
+    a, b = rng_pcm(1, n * ch), rng_pcm(2, n * ch, "white")
+    enc = gpu.QoaEncoder(gpu.QoaDesc(ch, 44100, n))
+    ref = oracle.OracleEncoder(ch, 44100, n)
+    assert enc.encode(a) == ref.encode(a)
+    assert enc.encode(b) == ref.encode(b)          # second one-shot on the same encoder: state is NOT reset
+    fl, frame = enc.encode_frame(a[: 700 * ch])
+    want, _ = ref.encode_frame(a[: 700 * ch])
+    assert (fl, frame) == (700, want)
+    assert enc.encode(a) == ref.encode(a)
+    assert np.array_equal(enc.lms_state(), np.array([h + w for h, w in ref.lms_state()], dtype=np.int32))
+    assert gpu.QoaEncoder(gpu.QoaDesc(ch, 44100, n)).write_header() == ref.write_header() == b"qoaf" + n.to_bytes(4, "big")
+
+
+def test_decoder_handle_flows(gpu, oracle):
+    """decode_frame() on a fixed-mode decoder, next() resuming after None once more bytes arrive, a frame split
+    across two decode_frame() calls, current_frame_header() tracking."""
+    x = rng_pcm(3, 5200 * 2)
+    stream = oracle.encode_all(x, 2, 32000, 5200)   # frames: 5120 + 80 sample-times
+    f0_end = 8 + 4136
+    # fixed-mode decoder built from the first frame only, second frame appended later
+    dec, ref = gpu.QoaDecoder(stream[:f0_end]), oracle.OracleDecoder(stream[:f0_end])
+    got = [dec.next() for _ in range(3)]
+    assert got[0] == gpu.FrameHeader(2, 32000, 5120) and isinstance(got[1], gpu.Sample)
+    want = [ref.next() for _ in range(3)]
+    assert [g.value for g in got[1:]] == [w[1] for w in want[1:]]
+    rest_gpu = dec.decode_frame(stream[f0_end:])     # drains frame 0's remaining samples + the appended frame
+    rest_ref = ref.decode_frame(stream[f0_end:])
+    assert np.array_equal(rest_gpu, rest_ref) and rest_gpu.size == 5200 * 2 - 2
+    assert dec.next() is None and dec.current_frame_header() == gpu.FrameHeader(2, 32000, 80)
+    # streaming decoder fed half a frame: IoError, as in the reference (the cursor is then at EOF)
+    sd, sr = gpu.QoaDecoder.new_streaming(), oracle.OracleDecoder(streaming=True)
+    with pytest.raises(gpu.DecodeError) as e:
+        sd.decode_frame(stream[8:8 + 2000])
+    assert e.value.kind == "IoError"
+    with pytest.raises(oracle.OracleError):
+        sr.decode_frame(stream[8:8 + 2000])
+    # iterator resumes after None when the reader grows (Cursor<Vec<u8>> semantics)
+    it = gpu.QoaDecoder.new_streaming()
+    assert it.next() == gpu.FrameHeader(0, 0, 0) and it.next() is None
+    tail = it.decode_frame(stream[f0_end:])
+    _, _, full = oracle.decode_all(stream)
+    assert np.array_equal(tail, full[5120 * 2:])
+    assert it.next() is None
+
+
+def test_degenerate_shapes(gpu, oracle):
+    for ch, n in ((8, 1), (1, 1), (8, 20), (7, 21), (3, 5121), (8, 5120)):
+        x = rng_pcm(ch * 100 + n, ch * n, "white")
+        enc = gpu.encode_all(x, gpu.QoaDesc(ch, 1, n))  # sample_rate 1 is the smallest legal value
+        assert enc == oracle.encode_all(x, ch, 1, n) and len(enc) == gpu.encoded_size(ch, n)
+        d = gpu.decode_all(enc)
+        _, _, want = oracle.decode_all(enc)
+        assert np.array_equal(d.samples, want)
