@@ -81,6 +81,30 @@ for _ in range(2):
 out["config3_pcie_inclusive_serial"] = {"h2d_ms": (t1 - t0) * 1e3, "h2d_GBps": plan.pcm_bytes / (t1 - t0) / 1e9, "kernel_ms": (t2 - t1) * 1e3,
                                         "d2h_ms": (t3 - t2) * 1e3, "d2h_GBps": plan.out_bytes / (t3 - t2) / 1e9,
                                         "samples_per_s_end_to_end": plan.samples / (t3 - t0)}
+# signal classes: the GPU kernel's cost is content-independent, the CPU's early exits are not
+cls = {}
+n_c, fr = 256, 64
+for kind in ("music", "white", "silence", "fixture"):
+    if kind == "fixture":
+        base = torch.from_numpy(d.samples[: fr * 5120 * 2].reshape(1, fr * 5120, 2).copy()).to(dev)
+        x = base.repeat((n_c, 1, 1)).contiguous()
+    else:
+        x = synth.make_clips(16, fr * 5120, 2, device=dev, kind=kind).repeat((n_c // 16, 1, 1)).contiguous()
+    dsc = q.QoaDesc(2, 44100, fr * 5120)
+    cl, _, pe = batch.uniform_clips(n_c, dsc)
+    pl = batch.EncodePlan(cl, batch.PLAN_CPW_4)
+    oo = torch.empty((n_c, pe), dtype=torch.uint8, device=dev)
+    pl.run(x, oo); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); pl.run(x, oo); e1.record(); torch.cuda.synchronize()
+    hx = x[0].cpu().numpy().reshape(-1)
+    enc1 = O.OracleEncoder(2, 44100, fr * 5120)
+    t0 = time.perf_counter(); ref = enc1.encode(hx); dtc = time.perf_counter() - t0
+    cls[kind] = {"gpu_kernel_ms_256clips_x_64frames": e0.elapsed_time(e1), "cpu_1thread_samples_per_s": hx.size / dtc,
+                 "cpu_candidate_steps_per_slice": enc1.candidate_steps / enc1.slices,
+                 "bit_exact": oo[0].cpu().numpy().tobytes() == ref}
+out["signal_classes"] = cls
+
 # the same from host memory through the time-sliced pipeline (qoa_encode_batch_host)
 host_out.zero_()
 for cf in (32, 16):
