@@ -102,7 +102,8 @@ int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state /* channels*8 */)
 
 /* Test hook: run ONE slice (src/lib.rs:495-596) from an explicit entry state through the device functions of
  * the encode kernel and return all 16 candidates: total rank, first-sample rank, packed slice (tail already
- * left-aligned) and end LMS state [16][8].  generic != 0 forces the rolled tail path.
+ * left-aligned) and end LMS state [16][8].  generic: 0 = production path (one-asm slice), 1 = rolled tail path,
+ * 2 = the same step as 20 separate statements.
  * first_rank[i] = (the row's winner << 32) | |err0| of candidate i (what orders the first-sample ranks). */
 int qoa_debug_encode_slice(const int32_t *state /* 8 */, const int16_t *samples, int len /* 1..20 */, int generic,
                            uint64_t *total_rank /* 16 */, uint64_t *first_rank /* 16 */, uint64_t *slices /* 16 */,

@@ -27,6 +27,7 @@
 
 #include "qoa_format.h"
 #include "qoa_kernels.h"
+#include "qoa_slice_asm.inc"
 
 namespace qoa {
 
@@ -181,6 +182,34 @@ __device__ __forceinline__ void run_slice_full(const int (&smp)[20], int sf, con
     r.e = e;
     r.pen = pen;
     // slice = sf<<60 | codes 0..9 <<30 | codes 10..19   (src/lib.rs:549,560,584)
+    r.s_hi = ((unsigned)sf << 28) | (acc_a >> 2);
+    r.s_lo = (acc_a << 30) | acc_b;
+}
+
+// The production path for a full slice: all 20 steps in ONE asm statement (text generated by
+// tools/gen_slice_asm.py from the same 42-instruction step as cand_step()).  Compared with 20 cand_step() statements
+// this drops the s_nop and s_waitcnt hipcc inserts at every asm boundary and the register copies around them;
+// the 20 samples are read from the LDS tile inside the block (`tile_addr` = LDS byte address of the slice).
+__device__ __forceinline__ void run_slice_asm(unsigned tile_addr, int sf, const StepConst &k, const Lms &entry,
+                                              CandResult &r) {
+    int w0 = entry.w0, w1 = entry.w1, w2 = entry.w2, w3 = entry.w3;
+    int h0 = entry.h0, h1 = entry.h1, h2 = entry.h2, h3 = entry.h3;
+    unsigned long long e;
+    unsigned pen, acc_a, acc_b, aerr0;
+    asm volatile(QOA_SLICE_ASM_TEXT
+                 : [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [w3] "+v"(w3), [h0] "+v"(h0), [h1] "+v"(h1),
+                   [h2] "+v"(h2), [h3] "+v"(h3), [e] "=&v"(e), [pen] "=&v"(pen), [acca] "=&v"(acc_a),
+                   [accb] "=&v"(acc_b), [aerr0] "=&v"(aerr0)
+                 : [tile] "v"(tile_addr), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768)
+                 : "vcc", "memory", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
+                   "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
+                   "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    r.lms.w0 = w0; r.lms.w1 = w1; r.lms.w2 = w2; r.lms.w3 = w3;
+    r.lms.h0 = h0; r.lms.h1 = h1; r.lms.h2 = h2; r.lms.h3 = h3; // 20 % 4 == 0: the ring is back in place
+    r.e = e;
+    r.pen = pen;
+    r.aerr0 = aerr0;
     r.s_hi = ((unsigned)sf << 28) | (acc_a >> 2);
     r.s_lo = (acc_a << 30) | acc_b;
 }
@@ -357,22 +386,21 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         const unsigned k0 = blk * kBlockSlices;
         const unsigned nj = min(nslices - k0, (unsigned)kBlockSlices);
         for (unsigned j = 0; j < nj; j++) {
-            int smp[20];
-            {
+            const int len = (int)min(samples - (k0 + j) * 20u, 20u);
+            const bool full = (len == 20) && !force_tail_path;
+
+            CandResult r;
+            if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
+                typedef __attribute__((address_space(3))) int *lds_ptr;
+                run_slice_asm((unsigned)(size_t)(lds_ptr)(tile + j * 20), sf, kc, st, r);
+            } else {
+                int smp[20];
                 const int4 *src = (const int4 *)(tile + j * 20); // same address in all 16 lanes: LDS broadcast
 #pragma unroll
                 for (int q = 0; q < 5; q++) {
                     const int4 v = src[q];
                     smp[4 * q] = v.x; smp[4 * q + 1] = v.y; smp[4 * q + 2] = v.z; smp[4 * q + 3] = v.w;
                 }
-            }
-            const int len = (int)min(samples - (k0 + j) * 20u, 20u);
-            const bool full = (len == 20) && !force_tail_path;
-
-            CandResult r;
-            if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
-                run_slice_full(smp, sf, kc, st, r);
-            } else {
                 run_slice_tail(smp, len, sf, kc, st, r);
             }
             const unsigned win = pick_winner(r, sf);
@@ -431,8 +459,21 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 #pragma unroll
     for (int i = 0; i < 20; i++) smp[i] = samples[i];
     CandResult r;
-    if (generic || len != 20) run_slice_tail(smp, len, sf, kc, st, r);
-    else run_slice_full(smp, sf, kc, st, r);
+    // generic: 0 = production (one-asm slice, samples staged in LDS), 1 = rolled tail path, 2 = 20 cand_step() statements
+    __shared__ __attribute__((aligned(16))) int s_dbg[20];
+    if (generic == 0 && len == 20) {
+        if (sf == 0) {
+#pragma unroll
+            for (int i = 0; i < 20; i++) s_dbg[i] = smp[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the 16 lanes of the wave see lane 0's LDS writes (in-order LDS)
+        typedef __attribute__((address_space(3))) int *lds_ptr;
+        run_slice_asm((unsigned)(size_t)(lds_ptr)s_dbg, sf, kc, st, r);
+    } else if (generic == 1 || len != 20) {
+        run_slice_tail(smp, len, sf, kc, st, r);
+    } else {
+        run_slice_full(smp, sf, kc, st, r);
+    }
     tot[sf] = r.e + r.pen;
     fst[sf] = ((unsigned long long)pick_winner(r, sf) << 32) | r.aerr0; // [63:32] winner of the row, [31:0] |err0|
     slice[sf] = ((unsigned long long)r.s_hi << 32) | r.s_lo;

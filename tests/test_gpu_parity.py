@@ -344,7 +344,7 @@ def test_kat2_slice_search_lane_by_lane(gpu, oracle):
            12013, 11809, 11685]
     want = [522117267, 525200405, 119383785, 43336318, 1587308, 1582747, 1887874, 1946592, 2513046, 3221590, 4272064,
             3964616, 6487859, 13440220, 24107150, 16356911]
-    for generic in (0, 1):
+    for generic in (0, 1, 2):  # one-asm slice, rolled tail path, 20 separate step statements
         tot, aerr0, sl, es, dev_win = _gpu_slice(state, smp, generic)
         assert tot == want
         win = min((tot[i], aerr0[i], i) for i in range(16))[2]
@@ -362,7 +362,7 @@ def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
         length = 20 if trial % 5 else int(r.integers(1, 20))
         smp = rng_pcm(trial, length, kind)
         s, sf, (eh, ew), totals = oracle.encode_slice(hist, w, smp)
-        for generic in (0, 1):
+        for generic in (0, 1, 2):
             tot, aerr0, sl, es, dev_win = _gpu_slice(hist + w, smp, generic)
             assert tot == totals, (trial, generic)
             win = min((tot[i], aerr0[i], i) for i in range(16))[2]

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=${1:-pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-CMD="tools/prof_driver 1024 256 2 2 2"
+CMD="tools/prof_driver 1024 256 2 2 1"
 i=0
 for grp in \
   "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" \
