@@ -38,10 +38,10 @@ def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
 
 def valu_issue(n_chains: int, samples: int, kernel_ms: float):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
-    Instruction count per slice is the PMC-measured 894 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4)."""
+    Instruction count per slice is the PMC-measured 902 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4)."""
     waves = (n_chains + 3) // 4
     slices = (samples + 19) // 20
-    achieved = 894.0 * slices * waves / (kernel_ms * 1e-3)
+    achieved = 902.0 * slices * waves / (kernel_ms * 1e-3)
     peak = 1024 * 2.4e9 / 4.0
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s",
             "frac": achieved / peak, "wavefronts": waves}
@@ -181,7 +181,7 @@ def main():
                      "traffic": pmc_traffic("encode", n_clips, ch, args.frames), "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md",
-                     # the bound that actually governs K1 (profiles/r01d_pmc_summary.txt): 894 VALU wave-instructions
+                     # the bound that actually governs K1 (profiles/r01e_pmc_summary.txt): 902 VALU wave-instructions
                      # per slice per wavefront, one per 4 cycles per SIMD at 2.4 GHz on 1024 SIMDs
                      "valu_issue": valu_issue(n_clips * ch, samples, k_avg_ms)},
     }
