@@ -102,9 +102,11 @@ int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state /* channels*8 */)
 
 /* Test hook: run ONE slice (src/lib.rs:495-596) from an explicit entry state through the device functions of
  * the encode kernel and return all 16 candidates: total rank, first-sample rank, packed slice (tail already
- * left-aligned) and end LMS state [16][8].  generic: 0 = production path (one-asm slice), 1 = rolled tail path,
- * 2 = the same step as 20 separate statements.
- * first_rank[i] = (the row's winner << 32) | |err0| of candidate i (what orders the first-sample ranks). */
+ * left-aligned) and end LMS state [16][8].  generic: 0 = one-asm slice with 32-bit weights, 1 = rolled tail
+ * path, 2 = the same step as 20 separate statements, 3 = the i16-packed fast path with its fall-back, as K1 runs it.
+ * first_rank[i] = (the row's winner << 32) | |err0| of candidate i (what orders the first-sample ranks); with
+ * generic == 3, bit 63 is set when the packed path declined the slice (state or weight energy out of its range)
+ * and the 32-bit path produced the results. */
 int qoa_debug_encode_slice(const int32_t *state /* 8 */, const int16_t *samples, int len /* 1..20 */, int generic,
                            uint64_t *total_rank /* 16 */, uint64_t *first_rank /* 16 */, uint64_t *slices /* 16 */,
                            int32_t *end_states /* 16*8 */);
@@ -128,6 +130,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 /* flags for qoa_encode_plan_create */
 #define QOA_PLAN_DEFAULT 0u
 #define QOA_PLAN_FORCE_GENERIC_PATH 1u /* debug: run the rolled tail-slice path for every slice */
+#define QOA_PLAN_FORCE_32BIT_STEP 2u   /* debug: never take the i16-packed fast path (same bytes, tests compare) */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
 #define QOA_PLAN_CPW_2 (2u << 4)
 #define QOA_PLAN_CPW_4 (4u << 4)

@@ -15,6 +15,7 @@ from .api import DecodeError, EncodeError, QoaDesc, encoded_size
 
 PLAN_DEFAULT = 0
 PLAN_FORCE_GENERIC_PATH = 1
+PLAN_FORCE_32BIT_STEP = 2
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 
 

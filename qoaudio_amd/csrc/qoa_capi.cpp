@@ -208,10 +208,12 @@ extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_
     return QOA_OK;
 }
 
-// kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352)
+// kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
+// bit2 no i16-packed fast path
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
-    unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u);
+    unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) |
+                      ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u);
     for (auto *g : plan->groups) {
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
                               kflags, (hipStream_t)stream),

@@ -81,7 +81,10 @@ struct CandResult {
 //
 //   predict   ((w0h0 + w1h1) + (w2h2 + w3h3)) >> 13, wrapping                      src/lib.rs:811-813
 //   penalty   max(0, ((w0w0 + w1w1 + w2w2 + w3w3) >> 18) - 0x8ff), squared, summed    src/lib.rs:814-817
-//   qoa_div   ((res * recip + 2^15) >> 16) + sgn(res) - sgn(n)                     src/lib.rs:613-617
+//   qoa_div   n = (res * recip + 2^15) >> 16; scaled = n + sgn(res) - sgn(n)       src/lib.rs:613-617
+//             computed as med3(n, n + 2a, a) with a = sgn(res): for a = +1 that is n (n > 0), 1 (n = 0) and
+//             n + 2 (n < 0, which only the i32 wrap of res * recip at sf 0/1 produces), mirrored for a = -1,
+//             and 0 for a = 0 (then n = 0) -- the same value in every case, one instruction fewer
 //   quantiser c = clamp(scaled,-8,8); level = min(|c|>>1,3); code = 2*level + (c<0); dequant = +-mag[level]
 //             (closed form of QOA_QUANT_TAB / QOA_DEQUANT_TAB, verified exhaustively in tests/test_capi_host.py;
 //             the lane's four magnitudes are packed in dq_lo/dq_hi and selected by v_perm_b32)
@@ -121,9 +124,8 @@ __device__ __forceinline__ void cand_step(int smp, const StepConst &k, Lms &l, i
         "v_med3_i32 %[t], %[t], -1, 1\n\t"                     // sgn(residual)
         "v_ashrrev_i32 %[u], 16, %[u]\n\t"                     // n
         "v_mad_i32_i24 %[pen], v126, v126, %[pen]\n\t"
-        "v_add_u32 %[t], %[u], %[t]\n\t"
-        "v_med3_i32 %[u], %[u], -1, 1\n\t"                     // sgn(n)
-        "v_sub_u32 %[u], %[t], %[u]\n\t"                       // scaled
+        "v_lshl_add_u32 %[sneg], %[t], 1, %[u]\n\t"            // n + 2 sgn(residual)
+        "v_med3_i32 %[u], %[u], %[sneg], %[t]\n\t"             // scaled
         "v_sub_u32 %[t], 0, %[u]\n\t"
         "v_ashrrev_i32 %[sneg], 31, %[u]\n\t"
         "v_max_i32 %[t], %[u], %[t]\n\t"                       // |scaled|
@@ -214,6 +216,80 @@ __device__ __forceinline__ void run_slice_asm(unsigned tile_addr, int sf, const 
     r.s_lo = (acc_a << 30) | acc_b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed fast path.  In practice every weight fits i16 (the penalty term exists to keep them there), and
+// the history always does (reconstructed samples are clamped).  Carrying them as i16 pairs turns the two
+// 4-term dot products into 2 + 2 v_dot2_i32_i16 and the four weight updates into 2 v_pk_mad_i16: 35
+// instructions per step instead of 41 (QOA_SLICE_PK_ASM_TEXT, tools/gen_slice_asm.py).
+//
+// Exactness.  With all |w_i| <= 32767 the products are exact and v_dot2_i32_i16 accumulates them modulo 2^32,
+// which is the reference's wrapping i32 sum (src/lib.rs:811-817).  The penalty is computed as
+// max(0, (S - (0x8ff << 18)) >> 18) with S = sum w_i^2; that equals max(0, (S >> 18) - 0x8ff) while S < 2^31.
+// Invariant: S < kPkEnergyLimit = 3875 << 18 at a step  =>  every |w_i| <= 31871  =>  after the update
+// (|delta| <= 14336 >> 4 = 896) every |w_i| <= 32767 and S <= 1.134e9 < 2^31, so the next step computes its S
+// and its penalty exactly, and if that S is no longer below the limit its penalty is >= 3875 - 0x8ff = 1572.
+// Hence: "penalty sum of a candidate < 1572^2" proves that all 20 steps of that candidate were exact, and that
+// its end state again satisfies what the next slice's first step needs.  A slice in which any candidate of the
+// wave fails the test is evaluated again by the 32-bit path from the same entry state (it never happens on
+// real audio or on the benchmark signals: profiles/r01f_redo_rate.txt).  After a 32-bit slice the state is
+// re-admitted by pk_try_pack(), which checks the ranges and the energy directly.
+// ------------------------------------------------------------------------------------------------
+struct PkLms {
+    unsigned w01, w23; // (w0, w1), (w2, w3): lower index in the low half
+    unsigned pa, pb;   // history (h0, h1), (h2, h3)
+};
+constexpr unsigned kPkPenLimit = 1572u * 1572u;
+constexpr long long kPkEnergyLimit = 3875ll << 18;
+
+struct PkResult {
+    PkLms lms;
+    unsigned long long e;
+    unsigned pen, aerr0, s_hi, s_lo;
+};
+
+__device__ __forceinline__ void pk_unpack(const PkLms &p, Lms &l) {
+    l.w0 = (int)(p.w01 << 16) >> 16; l.w1 = (int)p.w01 >> 16;
+    l.w2 = (int)(p.w23 << 16) >> 16; l.w3 = (int)p.w23 >> 16;
+    l.h0 = (int)(p.pa << 16) >> 16; l.h1 = (int)p.pa >> 16;
+    l.h2 = (int)(p.pb << 16) >> 16; l.h3 = (int)p.pb >> 16;
+}
+
+// Can this state enter the packed path?  (Same answer in the 16 lanes of a chain: they hold the same state.)
+__device__ __forceinline__ bool pk_try_pack(const Lms &l, PkLms &p) {
+    auto fits = [](int v) { return (unsigned)(v + 32768) < 65536u; };
+    auto pack = [](int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); };
+    const bool in_range = fits(l.w0) && fits(l.w1) && fits(l.w2) && fits(l.w3) && fits(l.h0) && fits(l.h1) &&
+                          fits(l.h2) && fits(l.h3);
+    const int c0 = med3(l.w0, -32768, 32767), c1 = med3(l.w1, -32768, 32767), c2 = med3(l.w2, -32768, 32767),
+              c3 = med3(l.w3, -32768, 32767); // clamped: the 64-bit sum below cannot overflow
+    const long long energy = (long long)c0 * c0 + (long long)c1 * c1 + (long long)c2 * c2 + (long long)c3 * c3;
+    p.w01 = pack(l.w0, l.w1); p.w23 = pack(l.w2, l.w3);
+    p.pa = pack(l.h0, l.h1); p.pb = pack(l.h2, l.h3);
+    return in_range && energy < kPkEnergyLimit;
+}
+
+__device__ __forceinline__ void run_slice_pk(unsigned tile_addr, int sf, const StepConst &k, const PkLms &entry,
+                                             PkResult &r) {
+    unsigned w01 = entry.w01, w23 = entry.w23, pa = entry.pa, pb = entry.pb;
+    unsigned long long e;
+    unsigned pen, acc_a, acc_b, aerr0;
+    asm volatile(QOA_SLICE_PK_ASM_TEXT
+                 : [w01] "+v"(w01), [w23] "+v"(w23), [pa] "+v"(pa), [pb] "+v"(pb), [e] "=&v"(e), [pen] "=&v"(pen),
+                   [acca] "=&v"(acc_a), [accb] "=&v"(acc_b), [aerr0] "=&v"(aerr0)
+                 : [tile] "v"(tile_addr), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),
+                   [negc] "s"(-(0x8ff << 18))
+                 : "vcc", "memory", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+                   "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+                   "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    r.lms.w01 = w01; r.lms.w23 = w23; r.lms.pa = pa; r.lms.pb = pb;
+    r.e = e;
+    r.pen = pen;
+    r.aerr0 = aerr0;
+    r.s_hi = ((unsigned)sf << 28) | (acc_a >> 2);
+    r.s_lo = (acc_a << 30) | acc_b;
+}
+
 // Any slice length 1..20 (the last slice of a clip).  Rolled loop; the sample window is shifted through
 // registers so nothing is runtime-indexed (a runtime index would put the array in scratch).  Codes are
 // placed at their final bit positions, which is the reference's tail shift (src/lib.rs:485-487) for free.
@@ -260,11 +336,11 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned v) {
 // Winner of a slice = argmin (total rank, first-sample rank, sf): the closed form of the reference's
 // rank-sorted candidate order with its two early exits (src/lib.rs:516-593).  total < 2^37; first-sample
 // ranks order like |err0| (16 bits) -- two 32-bit keys: tot>>5, then tot[4:0] : |err0| : sf.
-__device__ __forceinline__ unsigned pick_winner(const CandResult &r, int sf) {
-    const unsigned long long tot = r.e + r.pen;
+__device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned pen, unsigned aerr0, int sf) {
+    const unsigned long long tot = e + pen;
     const unsigned t_lo = (unsigned)tot, t_hi = (unsigned)(tot >> 32);
     const unsigned k1 = __builtin_amdgcn_alignbit(t_hi, t_lo, 5);
-    unsigned k2 = ((t_lo & 31u) << 20) | (r.aerr0 << 4) | (unsigned)sf;
+    unsigned k2 = ((t_lo & 31u) << 20) | (aerr0 << 4) | (unsigned)sf;
     const unsigned m1 = row_min_u32(k1);
     k2 = (k1 == m1) ? k2 : 0xffffffffu;
     return row_min_u32(k2) & 15u;
@@ -330,6 +406,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     kc.selbase = 0x0c0c0100u;
     kc.hi = 32767;
     const bool force_tail_path = (flags & 1u) != 0;
+    const bool allow_packed = (flags & 4u) == 0; // bit 2: 32-bit step only (tests compare the two)
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -340,6 +417,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         st.h0 = s[0]; st.h1 = s[1]; st.h2 = s[2]; st.h3 = s[3];
         st.w0 = s[4]; st.w1 = s[5]; st.w2 = s[6]; st.w3 = s[7];
     }
+
+    // The chain's state lives in `pk` while `packed` (st is then stale), in `st` otherwise.
+    PkLms pk;
+    bool packed = pk_try_pack(st, pk) && allow_packed;
 
     uint8_t *o = out + ch.out_off;
     if (ch.flags & 1u) { // file header "qoaf" + samples, big-endian (src/lib.rs:382-385)
@@ -375,6 +456,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 *(uint2 *)fo = make_uint2(bswap32(ch.hdr_hi), bswap32((frame_len << 16) | fsize));
             }
             uint2 *d = (uint2 *)(fo + 8 + 16 * ch.channel);
+            if (packed) pk_unpack(pk, st);
             d[0] = make_uint2(bswap32(((unsigned)st.h0 << 16) | ((unsigned)st.h1 & 0xffffu)),
                               bswap32(((unsigned)st.h2 << 16) | ((unsigned)st.h3 & 0xffffu)));
             d[1] = make_uint2(bswap32(((unsigned)st.w0 << 16) | ((unsigned)st.w1 & 0xffffu)),
@@ -389,10 +471,30 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);
             const bool full = (len == 20) && !force_tail_path;
 
+            typedef __attribute__((address_space(3))) int *lds_ptr;
+            const unsigned tile_addr = (unsigned)(size_t)(lds_ptr)(tile + j * 20);
+            if (__builtin_amdgcn_ballot_w64(!(full && packed)) == 0ull) { // every chain of the wave can go packed
+                PkResult pr;
+                run_slice_pk(tile_addr, sf, kc, pk, pr);
+                if (__builtin_amdgcn_ballot_w64(pr.pen >= kPkPenLimit) == 0ull) { // all 64 candidates provably exact
+                    const unsigned win = pick_winner(pr.e, pr.pen, pr.aerr0, sf);
+                    const int src_lane = (int)((row_base | win) << 2);
+                    const unsigned w_hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.s_hi);
+                    const unsigned w_lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.s_lo);
+                    pk.w01 = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.w01);
+                    pk.w23 = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.w23);
+                    pk.pa = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.pa);
+                    pk.pb = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.pb);
+                    if ((unsigned)sf == j) { keep_hi = w_hi; keep_lo = w_lo; }
+                    continue;
+                }
+                // else: fall through and evaluate the slice again with 32-bit weights from the same entry state
+            }
+            if (packed) pk_unpack(pk, st);
+
             CandResult r;
             if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
-                typedef __attribute__((address_space(3))) int *lds_ptr;
-                run_slice_asm((unsigned)(size_t)(lds_ptr)(tile + j * 20), sf, kc, st, r);
+                run_slice_asm(tile_addr, sf, kc, st, r);
             } else {
                 int smp[20];
                 const int4 *src = (const int4 *)(tile + j * 20); // same address in all 16 lanes: LDS broadcast
@@ -403,7 +505,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 }
                 run_slice_tail(smp, len, sf, kc, st, r);
             }
-            const unsigned win = pick_winner(r, sf);
+            const unsigned win = pick_winner(r.e, r.pen, r.aerr0, sf);
             const int src_lane = (int)((row_base | win) << 2);
 
             // LMS carry: every lane of the row takes the winner's end state (src/lib.rs:482);
@@ -419,6 +521,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             st.w2 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w2);
             st.w3 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w3);
             if ((unsigned)sf == j) { keep_hi = w_hi; keep_lo = w_lo; }
+            packed = pk_try_pack(st, pk) && allow_packed;
         }
     }
     { // flush the last (possibly partial) block
@@ -428,6 +531,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             *(uint2 *)so = make_uint2(bswap32(keep_hi), bswap32(keep_lo));
         }
     }
+    if (packed) pk_unpack(pk, st);
     if (sf == 0) {
         int32_t *s = lms_state + (size_t)chain_id * 8;
         s[0] = st.h0; s[1] = st.h1; s[2] = st.h2; s[3] = st.h3;
@@ -459,23 +563,39 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 #pragma unroll
     for (int i = 0; i < 20; i++) smp[i] = samples[i];
     CandResult r;
-    // generic: 0 = production (one-asm slice, samples staged in LDS), 1 = rolled tail path, 2 = 20 cand_step() statements
+    // generic: 0 = one-asm 32-bit slice (samples staged in LDS), 1 = rolled tail path, 2 = 20 cand_step() statements,
+    // 3 = packed fast path
     __shared__ __attribute__((aligned(16))) int s_dbg[20];
-    if (generic == 0 && len == 20) {
+    bool declined = false;
+    if ((generic == 0 || generic == 3 || generic == 4) && len == 20) {
         if (sf == 0) {
 #pragma unroll
             for (int i = 0; i < 20; i++) s_dbg[i] = smp[i];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the 16 lanes of the wave see lane 0's LDS writes (in-order LDS)
         typedef __attribute__((address_space(3))) int *lds_ptr;
-        run_slice_asm((unsigned)(size_t)(lds_ptr)s_dbg, sf, kc, st, r);
+        if (generic == 0) {
+            run_slice_asm((unsigned)(size_t)(lds_ptr)s_dbg, sf, kc, st, r);
+        } else { // the packed fast path, exactly as K1 uses it
+            PkLms pk;
+            PkResult pr;
+            declined = __builtin_amdgcn_ballot_w64(!pk_try_pack(st, pk)) != 0ull;
+            if (!declined) {
+                run_slice_pk((unsigned)(size_t)(lds_ptr)s_dbg, sf, kc, pk, pr);
+                declined = __builtin_amdgcn_ballot_w64(pr.pen >= kPkPenLimit) != 0ull;
+                pk_unpack(pr.lms, r.lms);
+                r.e = pr.e; r.pen = pr.pen; r.aerr0 = pr.aerr0; r.s_hi = pr.s_hi; r.s_lo = pr.s_lo;
+            }
+            if (declined && generic == 3) run_slice_asm((unsigned)(size_t)(lds_ptr)s_dbg, sf, kc, st, r); // what K1 does then
+        }
     } else if (generic == 1 || len != 20) {
         run_slice_tail(smp, len, sf, kc, st, r);
     } else {
         run_slice_full(smp, sf, kc, st, r);
     }
     tot[sf] = r.e + r.pen;
-    fst[sf] = ((unsigned long long)pick_winner(r, sf) << 32) | r.aerr0; // [63:32] winner of the row, [31:0] |err0|
+    // [35:32] winner of the row, [31:0] |err0|, bit 63: the packed path declined this slice (generic == 3)
+    fst[sf] = ((unsigned long long)declined << 63) | ((unsigned long long)pick_winner(r.e, r.pen, r.aerr0, sf) << 32) | r.aerr0;
     slice[sf] = ((unsigned long long)r.s_hi << 32) | r.s_lo;
     int32_t *o = end_state + sf * 8;
     o[0] = r.lms.h0; o[1] = r.lms.h1; o[2] = r.lms.h2; o[3] = r.lms.h3;

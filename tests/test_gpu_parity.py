@@ -129,13 +129,13 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic"])
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
     fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
-          "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4}[flags]
+          "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP}[flags]
     shapes = [(2, 5300), (1, 41), (2, 20), (3, 999), (2, 12000), (1, 6000), (8, 333), (2, 1), (1, 5120), (2, 5121),
               (5, 777), (2, 640), (1, 10240), (2, 319)]
     clips, pcm_parts, pcm_off, out_off = [], [], 0, 0
@@ -331,9 +331,12 @@ def _gpu_slice(state, smp, generic=0):
     rc = _lib.lib().qoa_debug_encode_slice(st.ctypes.data, s.ctypes.data, len(s), generic, tot.ctypes.data,
                                            fst.ctypes.data, sl.ctypes.data, es.ctypes.data)
     assert rc == 0
-    # fst[i] = (the device's own winner of the row << 32) | |err0| of candidate i
-    wins = {int(v) >> 32 for v in fst}
+    # fst[i] = (the device's own winner of the row << 32) | |err0| of candidate i; bit 63 = packed path declined
+    wins = {(int(v) >> 32) & 15 for v in fst}
     assert len(wins) == 1, "every lane must agree on the winner"
+    declined = {int(v) >> 63 for v in fst}
+    assert len(declined) == 1
+    _gpu_slice.declined = bool(declined.pop())
     return [int(v) for v in tot], [int(v) & 0xffffffff for v in fst], [int(v) for v in sl], es, wins.pop()
 
 
@@ -344,9 +347,10 @@ def test_kat2_slice_search_lane_by_lane(gpu, oracle):
            12013, 11809, 11685]
     want = [522117267, 525200405, 119383785, 43336318, 1587308, 1582747, 1887874, 1946592, 2513046, 3221590, 4272064,
             3964616, 6487859, 13440220, 24107150, 16356911]
-    for generic in (0, 1, 2):  # one-asm slice, rolled tail path, 20 separate step statements
+    for generic in (0, 1, 2, 3):  # one-asm slice, rolled tail path, 20 separate step statements, i16-packed slice
         tot, aerr0, sl, es, dev_win = _gpu_slice(state, smp, generic)
         assert tot == want
+        assert not _gpu_slice.declined
         win = min((tot[i], aerr0[i], i) for i in range(16))[2]
         assert (win, dev_win, hex(sl[win])) == (5, 5, "0x56484f1ce06cd14a")
 
@@ -362,7 +366,7 @@ def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
         length = 20 if trial % 5 else int(r.integers(1, 20))
         smp = rng_pcm(trial, length, kind)
         s, sf, (eh, ew), totals = oracle.encode_slice(hist, w, smp)
-        for generic in (0, 1, 2):
+        for generic in (0, 1, 2, 3):
             tot, aerr0, sl, es, dev_win = _gpu_slice(hist + w, smp, generic)
             assert tot == totals, (trial, generic)
             win = min((tot[i], aerr0[i], i) for i in range(16))[2]
@@ -370,6 +374,37 @@ def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
             shift = (20 - length) * 3
             assert sl[win] == (s << shift) & (2 ** 64 - 1)
             assert list(es[win]) == eh + ew
+
+
+def test_packed_fast_path_lane_by_lane(gpu, oracle):
+    """The i16-packed step (v_dot2_i32_i16 / v_pk_mad_i16) against the oracle, candidate by candidate: ordinary
+    weights, weights whose energy sits around the penalty threshold (sum w^2 ~ 0x8ff << 18, penalty active but the
+    slice still provably exact), weights at the edge of the admitted window and beyond it (the slice must then be
+    declined and re-done by the 32-bit path), history at the i16 extremes, residuals that wrap qoa_div at sf 0."""
+    r = np.random.default_rng(11)
+    accepted = declined = penalised = 0
+    for trial in range(240):
+        hist = [int(v) for v in r.integers(-32768, 32768, 4)]
+        if trial % 8 == 7:
+            hist = [[-32768, 32767][int(v)] for v in r.integers(0, 2, 4)]
+        amp = [3000, 9000, 12280, 12400, 13500, 15900, 16500, 31000][trial % 8]
+        w = [int(v) * int(sgn) for v, sgn in zip(r.integers(amp - amp // 8, amp + 1, 4), r.choice([-1, 1], 4))]
+        if trial % 16 == 0:
+            w = [0, 0, -8192, 16384]
+        smp = rng_pcm(1000 + trial, 20, ["white", "loud", "mix", "square"][trial % 4])
+        s, sf, (eh, ew), totals = oracle.encode_slice(hist, w, smp)
+        tot, aerr0, sl, es, dev_win = _gpu_slice(hist + w, smp, 3)
+        assert tot == totals, (trial, hist, w)
+        assert dev_win == sf and sl[sf] == s and list(es[sf]) == eh + ew
+        energy = sum(v * v for v in w)
+        if energy >= 3875 << 18:
+            assert _gpu_slice.declined
+        declined += _gpu_slice.declined
+        accepted += not _gpu_slice.declined
+        tot32, _, sl32, es32, _ = _gpu_slice(hist + w, smp, 0)
+        assert tot32 == tot and sl32 == sl and np.array_equal(es32, es)
+        penalised += (not _gpu_slice.declined) and energy >= (0x900 << 18)
+    assert accepted >= 100 and declined >= 40 and penalised >= 5, (accepted, declined, penalised)
 
 
 def test_rank_ties_resolved_like_the_reference(gpu, oracle):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates qoaudio_amd/csrc/qoa_slice_asm.inc: the full 20-step candidate evaluation of one slice as ONE
-inline-asm text (run: python tools/gen_slice_asm.py).  The step is the same 42-instruction sequence as
+inline-asm text (run: python tools/gen_slice_asm.py).  The step is the same 41-instruction sequence as
 cand_step() in qoa_kernels.hip; writing all 20 steps in one statement removes the s_nop / s_waitcnt pads hipcc puts
 at every asm-statement boundary and lets the history / sign rings rotate by register NAME (20 % 4 == 0, so
 after the slice every ring register again holds the element it started with).
@@ -39,9 +39,8 @@ def step(i):
         f"v_med3_i32 v{T}, v{T}, -1, 1",
         f"v_ashrrev_i32 v{U}, 16, v{U}",
         f"v_mad_i32_i24 %[pen], v{Q}, v{Q}, %[pen]",
-        f"v_add_u32 v{T}, v{U}, v{T}",
-        f"v_med3_i32 v{U}, v{U}, -1, 1",
-        f"v_sub_u32 v{U}, v{T}, v{U}",
+        f"v_lshl_add_u32 v{SNEG}, v{T}, 1, v{U}",           # n + 2 sgn(residual)
+        f"v_med3_i32 v{U}, v{U}, v{SNEG}, v{T}",            # scaled = n + sgn(residual) - sgn(n), see cand_step()
         f"v_sub_u32 v{T}, 0, v{U}",
         f"v_ashrrev_i32 v{SNEG}, 31, v{U}",
         f"v_max_i32 v{T}, v{U}, v{T}",
@@ -68,10 +67,111 @@ def step(i):
         f"v_mad_i32_i24 {w[3]}, {s[3]}, v{D}, {w[3]}",
         f"v_or_b32 {s[0]}, 1, {s[0]}",
     ]
-    assert len(L) == 42
+    assert len(L) == 41
     if i == 0:  # |err| of the first sample orders the first-sample ranks
         L += [f"v_sub_u32 v{U}, 0, v{T}", f"v_max_i32 %[aerr0], v{T}, v{U}"]
     return L
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Packed fast path: weights and history travel as i16 pairs, so the two 4-term dot products are 2 + 2 v_dot2_i32_i16
+# and the 4 weight updates are 2 v_pk_mad_i16 -- 35 instructions per step.  Valid only while every weight fits i16
+# and the weight energy stays below the bound the kernel checks after the slice (qoa_kernels.hip: kPkPenLimit).
+#
+# Pair ring: B_n = (h[n-2], h[n-1]) lives in R[n % 4]; step n reads A_n = B_(n-2) and B_n and writes
+# B_(n+1) = alignbit(recon_n, B_n, 16).  Sign ring S[] alike.  R0 = %[pb], R2 = %[pa] are the asm's in/out operands:
+# in (h2,h3) / (h0,h1), out (h18,h19) / (h16,h17) of the slice.
+#
+# Hazards the assembler does not pad inside an asm statement (gfx940/950): a v_dot2 result needs 3 other instructions
+# before a different VALU reads it; a packed (v_pk_*) result needs 1.  The slots are filled with work deferred from
+# the previous step (its error term) and with the sign pair of B_n.
+PK_P, PK_Q, PK_PR, PK_T, PK_U, PK_SN, PK_D, PK_X, PK_E = 116, 117, 118, 119, 120, 121, 122, 123, 91
+PK_R = ["%[pb]", "v124", "%[pa]", "v125"]
+PK_S = ["v126", "v127", "v94", "v95"]
+PK_RC = ["v92", "v93"]
+
+
+def pk_step(i):
+    R, S, RC = PK_R, PK_S, PK_RC
+    A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
+    SA, SB = S[(i + 2) % 4], S[i % 4]
+    smp = f"v{SMP0 + i}"
+    acc = "%[acca]" if i < 10 else "%[accb]"
+    rc = RC[i % 2]
+    P, Q, PR, T, U, SN, D, X, E = (f"v{r}" for r in (PK_P, PK_Q, PK_PR, PK_T, PK_U, PK_SN, PK_D, PK_X, PK_E))
+    if i == 0:
+        slot_a, slot_b = "v_mov_b32 %[acca], 0", "v_mov_b32 %[accb], 0"
+    else:
+        slot_a = f"v_sub_u32 {E}, v{SMP0 + i - 1}, {RC[(i - 1) % 2]}"      # err of the previous step
+        slot_b = f"v_mad_i64_i32 %[e], vcc, {E}, {E}, %[e]"
+    L = [
+        f"v_dot2_i32_i16 {P}, %[w01], {A}, 0",
+        f"v_dot2_i32_i16 {Q}, %[w01], %[w01], %[negc]",     # sum w^2 - (0x8ff << 18)
+        f"v_dot2_i32_i16 {P}, %[w23], {B}, {P}",
+        f"v_dot2_i32_i16 {Q}, %[w23], %[w23], {Q}",
+        f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",   # the inline 15 has no high half to select
+        slot_a,
+        f"v_or_b32 {SB}, 0x10001, {SB}",                    # (+-1, +-1) for B_n
+        f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
+        f"v_ashrrev_i32 {X}, 18, {Q}",
+        f"v_sub_u32 {T}, {smp}, {PR}",                      # residual
+        slot_b,
+        f"v_max_i32 {X}, 0, {X}",                           # penalty
+        f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
+        f"v_med3_i32 {T}, {T}, -1, 1",
+        f"v_mad_i32_i24 %[pen], {X}, {X}, %[pen]",
+        f"v_ashrrev_i32 {U}, 16, {U}",
+        f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
+        f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled
+        f"v_sub_u32 {T}, 0, {U}",
+        f"v_ashrrev_i32 {SN}, 31, {U}",
+        f"v_max_i32 {T}, {U}, {T}",
+        f"v_min_i32 {T}, 7, {T}",
+        f"v_and_b32 {T}, 6, {T}",
+        f"v_mad_u32_u24 {D}, {T}, %[c101], %[selb]",
+        f"v_lshl_add_u32 {acc}, {acc}, 3, {T}",
+        f"v_perm_b32 {D}, %[dqhi], %[dqlo], {D}",
+        f"v_sub_u32 {acc}, {acc}, {SN}",
+        f"v_xor_b32 {D}, {D}, {SN}",
+        f"v_sub_u32 {D}, {D}, {SN}",                        # dequantised
+        f"v_add_u32 {U}, {D}, {PR}",
+        f"v_ashrrev_i32 {D}, 4, {D}",                       # delta
+        f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
+        f"v_pk_mad_i16 %[w01], {SA}, {D}, %[w01] op_sel_hi:[1,0,1]",
+        f"v_pk_mad_i16 %[w23], {SB}, {D}, %[w23] op_sel_hi:[1,0,1]",
+        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
+    ]
+    assert len(L) == 35
+    if i == 1:  # |err| of the first sample, right after slot_a produced it
+        k = L.index(slot_a) + 1
+        L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 %[aerr0], {E}, {D}"]
+    return L
+
+
+def pk_slice():
+    lines = []
+    for k in range(5):
+        lines.append(f"ds_read_b128 v[{SMP0 + 4 * k}:{SMP0 + 4 * k + 3}], %[tile] offset:{16 * k}")
+    R, S = PK_R, PK_S
+    lines += [
+        f"v_alignbit_b32 {R[3]}, {R[0]}, {R[2]}, 16",        # B_(-1) = (h1, h2)
+        f"v_pk_ashrrev_i16 {S[2]}, 15, {R[2]} op_sel_hi:[0,1]",
+        f"v_pk_ashrrev_i16 {S[3]}, 15, {R[3]} op_sel_hi:[0,1]",
+        f"v_or_b32 {S[2]}, 0x10001, {S[2]}",
+        f"v_or_b32 {S[3]}, 0x10001, {S[3]}",
+        "v_mov_b64 %[e], 0",
+        "v_mov_b32 %[pen], 0",
+    ]
+    for i in range(20):
+        if i % 4 == 0:
+            lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
+        lines += pk_step(i)
+    lines += [f"v_sub_u32 v{PK_E}, v{SMP0 + 19}, {PK_RC[1]}", f"v_mad_i64_i32 %[e], vcc, v{PK_E}, v{PK_E}, %[e]"]
+    return lines
+
+
+def emit(name, lines):
+    return f"#define {name} \\\n" + " \\\n".join(f'    "{l}\\n\\t"' for l in lines) + "\n"
 
 
 def main():
@@ -85,12 +185,15 @@ def main():
         if i % 4 == 0:
             lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
         lines += step(i)
-    out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.  20 x 42-instruction candidate steps of one slice.\n"
-           "#define QOA_SLICE_ASM_TEXT \\\n" + " \\\n".join(f'    "{l}\\n\\t"' for l in lines) + "\n")
+    pk = pk_slice()
+    out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
+           "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
+           "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
+           + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
     with open(path, "w") as f:
         f.write(out)
-    print(f"wrote {path}: {len(lines)} lines")
+    print(f"wrote {path}: {len(lines)} + {len(pk)} lines")
 
 
 if __name__ == "__main__":
