@@ -290,6 +290,32 @@ __device__ __forceinline__ void run_slice_pk(unsigned tile_addr, int sf, const S
     r.s_lo = (acc_a << 30) | acc_b;
 }
 
+// `n` consecutive full slices of a block on the packed path in ONE statement (QOA_BLOCK_PK_ASM_TEXT): candidate steps,
+// winner election, exchange of the winner's state through the chain's 16 LDS slots (`cand` = this lane's slot, slots
+// are 16 bytes, a row's 16 slots are 256-byte aligned) and staging of the winner's slice words at `outb + 8 * i`
+// (the others write to `dummy`).  Returns how many slices were completed; fewer than n means slice number `done`
+// failed the kPkPenLimit test -- `pk` then holds that slice's entry state and the caller takes the 32-bit path.
+__device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned cand, unsigned outb, unsigned dummy, int sf,
+                                                 const StepConst &k, unsigned n, PkLms &pk) {
+    register unsigned w01 asm("v84") = pk.w01;
+    register unsigned w23 asm("v85") = pk.w23;
+    register unsigned pa asm("v86") = pk.pa;
+    register unsigned pb asm("v87") = pk.pb;
+    unsigned done;
+    asm volatile(QOA_BLOCK_PK_ASM_TEXT
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
+                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
+                   [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
+                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0xf0)
+                 : "vcc", "scc", "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
+                   "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
+                   "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
+                   "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
+    return done;
+}
+
 // Any slice length 1..20 (the last slice of a clip).  Rolled loop; the sample window is shifted through
 // registers so nothing is runtime-indexed (a runtime index would put the array in scratch).  Codes are
 // placed at their final bit positions, which is the reference's tail shift (src/lib.rs:485-487) for free.
@@ -381,7 +407,10 @@ template <int CPW, int NCH>
 __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restrict__ pcm, uint8_t *__restrict__ out,
                                                          const EncChain *__restrict__ chains, unsigned n_chains,
                                                          int32_t *__restrict__ lms_state, unsigned flags) {
-    __shared__ __attribute__((aligned(16))) int s_smp[4][CPW][kTileInts];
+    // sample tiles [wave][chain][kTileInts] + one slice of slack: the block loop prefetches one slice past its last
+    __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts + 20];
+    __shared__ __attribute__((aligned(256))) uint4 s_cand[4][CPW][16]; // candidate end states of the slice in flight
+    __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][32];   // [0,16): the block's winning slices, then dummies
     const unsigned lane = threadIdx.x & 63u;
     const unsigned grp = lane >> 4;
     if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle
@@ -391,7 +420,11 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     if (chain_id >= n_chains) return;
     const int sf = (int)(lane & 15u);
     const unsigned row_base = lane & ~15u;
-    int *tile = s_smp[wave_in_block][grp];
+    int *tile = s_smp + (wave_in_block * CPW + grp) * kTileInts;
+    uint2 *out_tile = s_out[wave_in_block][grp];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[wave_in_block][grp][sf];
+    const unsigned outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
 
     const EncChain ch = chains[chain_id];
     if (ch.samples == 0) return; // a clip that has no frames in this time slice (host pipeline): state untouched
@@ -430,7 +463,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     constexpr unsigned kFrameBytes = 8 + 16 * NCH + 8 * kSlicesPerFrame * NCH; // a full frame
 
     int pre[20];                       // lane j: samples of slice 16*(blk+1)+j, in flight during block blk
-    unsigned keep_hi = 0, keep_lo = 0; // lane j: finished slice of row 16*blk+j
+    // the winning slice of row 16*blk+j waits in out_tile[j] (LDS) for the flush at the next block top
     load_block_lane<NCH>(p, (unsigned)sf, samples, pre);
 
     for (unsigned blk = 0; blk < nblocks; blk++) {
@@ -443,7 +476,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         if (blk > 0) { // flush the previous block's 16 slices (always a full block)
             const unsigned k = (blk - 1) * kBlockSlices + (unsigned)sf;
             uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
-            *(uint2 *)so = make_uint2(bswap32(keep_hi), bswap32(keep_lo));
+            const uint2 kept = out_tile[sf];
+            *(uint2 *)so = make_uint2(bswap32(kept.x), bswap32(kept.y));
         }
         if ((blk & 15u) == 0 && sf == 0) {
             // frame header + this channel's LMS state at frame entry (src/lib.rs:448-466)
@@ -467,7 +501,16 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         // ---------------- 16 slices, no vector memory ----------------
         const unsigned k0 = blk * kBlockSlices;
         const unsigned nj = min(nslices - k0, (unsigned)kBlockSlices);
-        for (unsigned j = 0; j < nj; j++) {
+        unsigned j = 0;
+        {   // a block whose 16 slices are full in every chain of the wave, all chains packed: one statement does it
+            const bool whole = packed && !force_tail_path && (k0 + kBlockSlices) * 20u <= samples;
+            if (__builtin_amdgcn_ballot_w64(!whole) == 0ull) {
+                typedef __attribute__((address_space(3))) int *lds_int;
+                j = run_block_pk((unsigned)(size_t)(lds_int)tile, cand_addr, outb_addr, outb_addr + 8u * (16u + (unsigned)sf),
+                                 sf, kc, kBlockSlices, pk);
+            }
+        }
+        for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);
             const bool full = (len == 20) && !force_tail_path;
 
@@ -485,7 +528,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     pk.w23 = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.w23);
                     pk.pa = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.pa);
                     pk.pb = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane, (int)pr.lms.pb);
-                    if ((unsigned)sf == j) { keep_hi = w_hi; keep_lo = w_lo; }
+                    if ((unsigned)sf == j) out_tile[j] = make_uint2(w_hi, w_lo);
                     continue;
                 }
                 // else: fall through and evaluate the slice again with 32-bit weights from the same entry state
@@ -520,7 +563,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             st.w1 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w1);
             st.w2 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w2);
             st.w3 = __builtin_amdgcn_ds_bpermute(src_lane, r.lms.w3);
-            if ((unsigned)sf == j) { keep_hi = w_hi; keep_lo = w_lo; }
+            if ((unsigned)sf == j) out_tile[j] = make_uint2(w_hi, w_lo);
             packed = pk_try_pack(st, pk) && allow_packed;
         }
     }
@@ -528,7 +571,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         const unsigned k = (nblocks - 1) * kBlockSlices + (unsigned)sf;
         if (k < nslices) {
             uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
-            *(uint2 *)so = make_uint2(bswap32(keep_hi), bswap32(keep_lo));
+            const uint2 kept = out_tile[sf];
+            *(uint2 *)so = make_uint2(bswap32(kept.x), bswap32(kept.y));
         }
     }
     if (packed) pk_unpack(pk, st);

@@ -91,24 +91,33 @@ PK_S = ["v126", "v127", "v94", "v95"]
 PK_RC = ["v92", "v93"]
 
 
-def pk_step(i):
-    R, S, RC = PK_R, PK_S, PK_RC
+PK_OPERANDS = dict(w01="%[w01]", w23="%[w23]", pen="%[pen]", e="%[e]", acca="%[acca]", accb="%[accb]", aerr0="%[aerr0]",
+                   R=PK_R)
+# The block loop keeps everything that lives across slices in fixed registers (the statement's in/out operands are
+# register variables bound to v[84:87]): v[80:81] slice words, v[82:83] rank, v[84:87] packed state.
+PK_FIXED = dict(w01="v84", w23="v85", pen="v88", e="v[82:83]", acca="v89", accb="v90", aerr0="v79",
+                R=["v87", "v124", "v86", "v125"])
+
+
+def pk_step(i, N=PK_OPERANDS):
+    R, S, RC = N["R"], PK_S, PK_RC
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
     smp = f"v{SMP0 + i}"
-    acc = "%[acca]" if i < 10 else "%[accb]"
+    acc = N["acca"] if i < 10 else N["accb"]
+    w01, w23, pen, e = N["w01"], N["w23"], N["pen"], N["e"]
     rc = RC[i % 2]
     P, Q, PR, T, U, SN, D, X, E = (f"v{r}" for r in (PK_P, PK_Q, PK_PR, PK_T, PK_U, PK_SN, PK_D, PK_X, PK_E))
     if i == 0:
-        slot_a, slot_b = "v_mov_b32 %[acca], 0", "v_mov_b32 %[accb], 0"
+        slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"
     else:
         slot_a = f"v_sub_u32 {E}, v{SMP0 + i - 1}, {RC[(i - 1) % 2]}"      # err of the previous step
-        slot_b = f"v_mad_i64_i32 %[e], vcc, {E}, {E}, %[e]"
+        slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}"
     L = [
-        f"v_dot2_i32_i16 {P}, %[w01], {A}, 0",
-        f"v_dot2_i32_i16 {Q}, %[w01], %[w01], %[negc]",     # sum w^2 - (0x8ff << 18)
-        f"v_dot2_i32_i16 {P}, %[w23], {B}, {P}",
-        f"v_dot2_i32_i16 {Q}, %[w23], %[w23], {Q}",
+        f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
+        f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]",       # sum w^2 - (0x8ff << 18)
+        f"v_dot2_i32_i16 {P}, {w23}, {B}, {P}",
+        f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}",
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",   # the inline 15 has no high half to select
         slot_a,
         f"v_or_b32 {SB}, 0x10001, {SB}",                    # (+-1, +-1) for B_n
@@ -119,7 +128,7 @@ def pk_step(i):
         f"v_max_i32 {X}, 0, {X}",                           # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1",
-        f"v_mad_i32_i24 %[pen], {X}, {X}, %[pen]",
+        f"v_mad_i32_i24 {pen}, {X}, {X}, {pen}",
         f"v_ashrrev_i32 {U}, 16, {U}",
         f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
         f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled
@@ -137,37 +146,124 @@ def pk_step(i):
         f"v_add_u32 {U}, {D}, {PR}",
         f"v_ashrrev_i32 {D}, 4, {D}",                       # delta
         f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
-        f"v_pk_mad_i16 %[w01], {SA}, {D}, %[w01] op_sel_hi:[1,0,1]",
-        f"v_pk_mad_i16 %[w23], {SB}, {D}, %[w23] op_sel_hi:[1,0,1]",
+        f"v_pk_mad_i16 {w01}, {SA}, {D}, {w01} op_sel_hi:[1,0,1]",
+        f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
         f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
     ]
     assert len(L) == 35
     if i == 1:  # |err| of the first sample, right after slot_a produced it
         k = L.index(slot_a) + 1
-        L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 %[aerr0], {E}, {D}"]
+        L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     return L
 
 
-def pk_slice():
-    lines = []
-    for k in range(5):
-        lines.append(f"ds_read_b128 v[{SMP0 + 4 * k}:{SMP0 + 4 * k + 3}], %[tile] offset:{16 * k}")
-    R, S = PK_R, PK_S
-    lines += [
+def pk_prologue(N):
+    R, S = N["R"], PK_S
+    return [
         f"v_alignbit_b32 {R[3]}, {R[0]}, {R[2]}, 16",        # B_(-1) = (h1, h2)
         f"v_pk_ashrrev_i16 {S[2]}, 15, {R[2]} op_sel_hi:[0,1]",
         f"v_pk_ashrrev_i16 {S[3]}, 15, {R[3]} op_sel_hi:[0,1]",
         f"v_or_b32 {S[2]}, 0x10001, {S[2]}",
         f"v_or_b32 {S[3]}, 0x10001, {S[3]}",
-        "v_mov_b64 %[e], 0",
-        "v_mov_b32 %[pen], 0",
+        f"v_mov_b64 {N['e']}, 0",
+        f"v_mov_b32 {N['pen']}, 0",
     ]
+
+
+def sample_reads(addr):
+    return [f"ds_read_b128 v[{SMP0 + 4 * k}:{SMP0 + 4 * k + 3}], {addr} offset:{16 * k}" for k in range(5)]
+
+
+def pk_slice():
+    N = PK_OPERANDS
+    lines = sample_reads("%[tile]") + pk_prologue(N)
     for i in range(20):
         if i % 4 == 0:
             lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
-        lines += pk_step(i)
-    lines += [f"v_sub_u32 v{PK_E}, v{SMP0 + 19}, {PK_RC[1]}", f"v_mad_i64_i32 %[e], vcc, v{PK_E}, v{PK_E}, %[e]"]
+        lines += pk_step(i, N)
+    lines += [f"v_sub_u32 v{PK_E}, v{SMP0 + 19}, {PK_RC[1]}", f"v_mad_i64_i32 {N['e']}, vcc, v{PK_E}, v{PK_E}, {N['e']}"]
     return lines
+
+
+def pk_block():
+    """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
+    the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
+    must decline, with the slice's entry state restored.
+
+    Winner election = two 16-lane DPP min reductions (keys: rank >> 5, then rank[7:0] : |err0| : sf << 4).  The two
+    wait states a DPP read needs after a VALU write of its source are filled with the slice-word packing, the loop
+    counter and the NEXT slice's five sample reads, so the reads' latency is off the serial chain too.
+    Exchange: every candidate parks its end state in its own 16-byte LDS slot before the election; afterwards all 16
+    lanes read the winner's slot ((key2 & 0xf0) selects it: slots are 16 bytes, rows 256-byte aligned)."""
+    N = PK_FIXED
+    K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"
+    TCUR, OCUR = "v78", "v77"
+    SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
+    dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
+    L = []
+    L += [
+        "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an early exit restores
+        f"v_mov_b32 {TCUR}, %[tile]",
+        f"v_subrev_u32 {OCUR}, 8, %[outb]",
+        f"v_mov_b32 {ADDR}, %[cand]",
+    ] + sample_reads("%[tile]") + [
+        "s_mov_b32 %[done], 0",
+        "s_waitcnt lgkmcnt(0)",
+        "Lqoa_top_%=:",
+        "s_waitcnt lgkmcnt(1)",                              # the winner's state (only a slice-word store may trail)
+    ]
+    L += pk_prologue(N)
+    for i in range(20):
+        L += pk_step(i, N)
+    E = f"v{PK_E}"
+    L += [
+        f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
+        f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
+        f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
+        f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
+        "s_cbranch_vccnz Lqoa_declined_%=",
+        "ds_write_b128 %[cand], v[84:87]",
+        f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
+        f"v_lshlrev_b32 {K2}, 24, {ELO}",
+        f"v_mov_b32 {M}, {K1}",
+        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, {K2}",
+        f"v_or_b32 {K2}, %[sf4], {K2}",
+        dpp(M, 8),
+        f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
+        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
+        dpp(M, 4),
+        f"v_or_b32 {SHI}, %[sfsh], {SHI}",
+        f"v_add_u32 {TCUR}, 80, {TCUR}",
+        dpp(M, 2),
+        f"ds_read_b128 v[{SMP0}:{SMP0 + 3}], {TCUR} offset:0",
+        f"ds_read_b128 v[{SMP0 + 4}:{SMP0 + 7}], {TCUR} offset:16",
+        dpp(M, 1),
+        f"v_cmp_eq_u32 vcc, {K1}, {M}",
+        f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
+        f"ds_read_b128 v[{SMP0 + 8}:{SMP0 + 11}], {TCUR} offset:32",
+        f"ds_read_b128 v[{SMP0 + 12}:{SMP0 + 15}], {TCUR} offset:48",
+        dpp(K2, 8),
+        f"ds_read_b128 v[{SMP0 + 16}:{SMP0 + 19}], {TCUR} offset:64",
+        f"v_add_u32 {OCUR}, 8, {OCUR}",
+        dpp(K2, 4),
+        "s_add_u32 %[done], %[done], 1",
+        "s_cmp_lt_u32 %[done], %[n]",
+        dpp(K2, 2),
+        "s_nop 1",
+        dpp(K2, 1),
+        f"v_bfi_b32 {ADDR}, %[mf0], {K2}, %[cand]",          # the winner's slot
+        f"ds_read_b128 v[84:87], {ADDR}",
+        f"v_cmp_eq_u32 vcc, {ADDR}, %[cand]",
+        f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
+        f"ds_write_b64 {OADDR}, v[80:81]",
+        "s_cbranch_scc1 Lqoa_top_%=",
+        "s_branch Lqoa_end_%=",
+        "Lqoa_declined_%=:",
+        f"ds_read_b128 v[84:87], {ADDR}",                    # entry state of the declined slice
+        "Lqoa_end_%=:",
+        "s_waitcnt lgkmcnt(0)",
+    ]
+    return L
 
 
 def emit(name, lines):
@@ -186,14 +282,18 @@ def main():
             lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
         lines += step(i)
     pk = pk_slice()
+    blk = pk_block()
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
-           + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk))
+           "// QOA_BLOCK_PK_ASM_TEXT: a loop over consecutive full slices on the packed path incl. winner election and\n"
+           "//   state exchange; fixed registers v76-v127, state in v[84:87].\n"
+           + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk) + "\n"
+           + emit("QOA_BLOCK_PK_ASM_TEXT", blk))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
     with open(path, "w") as f:
         f.write(out)
-    print(f"wrote {path}: {len(lines)} + {len(pk)} lines")
+    print(f"wrote {path}: {len(lines)} + {len(pk)} + {len(blk)} lines")
 
 
 if __name__ == "__main__":

@@ -61,6 +61,15 @@ KERNEL(k_sad, "v_sad_u32 %0, %0, %1, %2\n")
 KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2\n")
 KERNEL(k_mul_u24_hi, "v_mul_hi_i32_i24 %0, %0, %1\n")
 
+KERNEL(k_add_e64_ind, "v_add_u32_e64 %0, %0, %1\n v_add_u32_e64 %2, %2, %1\n v_add_u32_e64 %3, %3, %1\n v_add_u32_e64 %4, %4, %1\n")
+KERNEL(k_or_lit_ind, "v_or_b32 %0, 0x10001, %0\n v_or_b32 %2, 0x10001, %2\n v_or_b32 %3, 0x10001, %3\n v_or_b32 %4, 0x10001, %4\n")
+KERNEL(k_mix_23, "v_add_u32 %0, %0, %1\n v_mad_i32_i24 %2, %2, %1, %5\n v_add_u32 %3, %3, %1\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_dot2c_ind, "v_dot2c_i32_i16 %0, %1, %5\n v_dot2c_i32_i16 %2, %1, %5\n v_dot2c_i32_i16 %3, %1, %5\n v_dot2c_i32_i16 %4, %1, %5\n")
+KERNEL(k_dpp_filled, "v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_med3_ind, "v_med3_i32 %0, %0, %1, %5\n v_med3_i32 %2, %2, %1, %5\n v_med3_i32 %3, %3, %1, %5\n v_med3_i32 %4, %4, %1, %5\n")
+KERNEL(k_snop1, "s_nop 1\n")
+KERNEL(k_mov_ind, "v_mov_b32 %0, %1\n v_mov_b32 %2, %1\n v_mov_b32 %3, %1\n v_mov_b32 %4, %1\n")
+
 struct T { const char *name; void (*k)(unsigned long long *, int *, int); int per_body; };
 
 int main() {
@@ -78,6 +87,9 @@ int main() {
         {"v_dot2_i32_i16 dep", k_dot2_dep, 1}, {"v_dot2_i32_i16 4-indep", k_dot2_ind, 4}, {"v_dot4_i32_i8 dep", k_dot4_dep, 1},
         {"ds_bpermute+wait", k_bperm, 1}, {"ds_bpermute 4-pipe", k_bperm_pipe, 4}, {"v_readlane+nop+add", k_readlane, 3},
         {"v_fma_f32 dep", k_fma_dep, 1}, {"v_fma_f32 4-indep", k_fma_ind, 4}, {"s_nop 0", k_snop, 1}, {"s_add_u32", k_salu, 1}, {"v_add+s_add", k_mix_valu_salu, 2},
+        {"v_add_u32_e64 4-indep", k_add_e64_ind, 4}, {"v_or_b32 literal 4-indep", k_or_lit_ind, 4}, {"add/mad24 alternating", k_mix_23, 4},
+        {"v_dot2c (VOP2) 4-indep", k_dot2c_ind, 4}, {"2 add + dpp (hazard filled)", k_dpp_filled, 3}, {"v_med3 4-indep", k_med3_ind, 4},
+        {"s_nop 1", k_snop1, 1}, {"v_mov_b32 4-indep", k_mov_ind, 4},
         {"v_sad_u32 dep", k_sad, 1}, {"v_xad_u32 dep", k_xad, 1}, {"v_mul_hi_i32_i24 dep", k_mul_u24_hi, 1},
     };
     printf("%-28s %12s %12s %12s   (cycles per instruction, s_memtime ticks)\n", "test", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
