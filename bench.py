@@ -38,10 +38,11 @@ def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
 
 def valu_issue(n_chains: int, samples: int, kernel_ms: float):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
-    Instruction count per slice is the PMC-measured 902 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4)."""
+    Instruction count per slice is the PMC-measured 744 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4,
+    profiles/r01f_pmc_summary.txt); a lone wavefront per SIMD can issue at most one instruction per 4 cycles."""
     waves = (n_chains + 3) // 4
     slices = (samples + 19) // 20
-    achieved = 902.0 * slices * waves / (kernel_ms * 1e-3)
+    achieved = 744.0 * slices * waves / (kernel_ms * 1e-3)
     peak = 1024 * 2.4e9 / 4.0
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s",
             "frac": achieved / peak, "wavefronts": waves}
@@ -181,7 +182,7 @@ def main():
                      "traffic": pmc_traffic("encode", n_clips, ch, args.frames), "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md",
-                     # the bound that actually governs K1 (profiles/r01e_pmc_summary.txt): 902 VALU wave-instructions
+                     # the bound that actually governs K1 (profiles/r01f_pmc_summary.txt): 744 VALU wave-instructions
                      # per slice per wavefront, one per 4 cycles per SIMD at 2.4 GHz on 1024 SIMDs
                      "valu_issue": valu_issue(n_clips * ch, samples, k_avg_ms)},
     }
@@ -193,6 +194,9 @@ def main():
         he = out[:2].cpu().numpy()
         ok = all(he[i].tobytes() == O.encode_all(hp[i].reshape(-1), ch, args.rate, samples) for i in range(2))
         result["bit_exact_vs_oracle"] = bool(ok)
+        declined, unpacked = plan.stats()  # K1's i16-packed fast path: slices it handed to the 32-bit path, all launches
+        result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked,
+                                 "slices_total": (args.warmup + args.steps) * n_clips * ch * ((samples + 19) // 20)}
         if world > 1 and gathered is not None:
             result["gathered_bytes"] = int(gathered.numel())
 

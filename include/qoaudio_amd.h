@@ -144,6 +144,12 @@ int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint
 /* Enqueue the encode of the whole batch on `stream` (a hipStream_t, may be NULL).  d_pcm and
  * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
 int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);
+/* Diagnostics of the plan's runs so far (synchronises the device).  *declined_slices = (chain, slice) pairs for which
+ * the kernel's i16-packed fast path could not prove its result exact and the 32-bit path evaluated the slice again;
+ * *unpacked_slices = full slices that went straight to the 32-bit path because a chain's LMS state was outside the
+ * packed path's range (|weight| > 32767 or weight energy too high).  Both are 0 on ordinary audio; neither affects
+ * the bytes produced.  Either pointer may be null. */
+int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices);
 
 /* ---- batch encode on HOST-resident buffers: time-sliced pipeline ----
  * Semantically encode_all per clip (src/lib.rs:760-763) with h_pcm / h_out in host memory (pinned memory makes

@@ -71,6 +71,15 @@ class EncodePlan:
         if rc:
             raise EncodeError(rc)
 
+    def stats(self) -> Tuple[int, int]:
+        """(declined, unpacked): (chain, slice) pairs the kernel's i16-packed fast path handed to the 32-bit path,
+        summed over the plan's runs so far.  Diagnostics only (synchronises the device); 0, 0 on ordinary audio."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        rc = _lib.lib().qoa_encode_plan_stats(self._h, C.byref(a), C.byref(b))
+        if rc:
+            raise EncodeError(rc)
+        return a.value, b.value
+
 
 class DecodePlan:
     """Frame table for a batch of encoded streams, resident on the current device."""

@@ -138,6 +138,7 @@ struct qoa_encode_plan {
     std::vector<EncGroup *> groups;
     uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;
     uint32_t flags = 0;
+    DevBuf stats; // 2 x u64, accumulated over every run of the plan
     ~qoa_encode_plan() { for (auto *g : groups) delete g; }
 };
 
@@ -177,6 +178,14 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
     plan->out_bytes = out_bytes;
     plan->samples = samples;
     plan->flags = flags;
+    {
+        hipError_t e = plan->stats.reserve(2 * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemset(plan->stats.p, 0, 2 * sizeof(uint64_t));
+        if (e != hipSuccess) {
+            delete plan;
+            return fail_hip(e, "encode plan counters", QOA_ENCODE_IO_ERROR);
+        }
+    }
     for (int nch = 1; nch <= kMaxChannels; nch++) {
         auto &v = per_nch[nch];
         if (v.empty()) continue;
@@ -216,9 +225,19 @@ extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, 
                       ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u);
     for (auto *g : plan->groups) {
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
-                              kflags, (hipStream_t)stream),
+                              kflags, (unsigned long long *)plan->stats.p, (hipStream_t)stream),
                 QOA_ENCODE_IO_ERROR);
     }
+    return QOA_OK;
+}
+
+extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices) {
+    if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
+    uint64_t h[2] = {0, 0};
+    HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR); // runs may be in flight on any stream; this is a diagnostic
+    HIP_TRY(hipMemcpy(h, plan->stats.p, sizeof h, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    if (declined_slices) *declined_slices = h[0];
+    if (unpacked_slices) *unpacked_slices = h[1];
     return QOA_OK;
 }
 
@@ -348,7 +367,7 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
                 if (!n) continue;
                 HIP_TRY(launch_encode(pick_cpw(n, 0), nch, (const int16_t *)P.pcm[b].p, (uint8_t *)P.enc[b].p,
                                       (const EncChain *)P.chains[b].p + group_begin[nch], n,
-                                      (int32_t *)P.lms.p + (size_t)group_begin[nch] * 8, j == 0 ? 2u : 0u, P.s_k),
+                                      (int32_t *)P.lms.p + (size_t)group_begin[nch] * 8, j == 0 ? 2u : 0u, nullptr, P.s_k),
                         QOA_ENCODE_IO_ERROR);
             }
             HIP_TRY(hipEventRecord(P.k_done[b], P.s_k), QOA_ENCODE_IO_ERROR);
@@ -461,7 +480,7 @@ static int encoder_run(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint3
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(enc->pcm.p, pcm, n_i16 * 2, hipMemcpyHostToDevice, enc->stream), QOA_ENCODE_IO_ERROR);
     HIP_TRY(launch_encode(1, enc->desc.channels, (const int16_t *)enc->pcm.p, (uint8_t *)enc->out.p,
-                          (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u,
+                          (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u, nullptr,
                           enc->stream),
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(out, enc->out.p, out_bytes, hipMemcpyDeviceToHost, enc->stream), QOA_ENCODE_IO_ERROR);

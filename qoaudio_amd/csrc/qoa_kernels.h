@@ -9,8 +9,12 @@ namespace qoa {
 
 // flags bit0: run every slice through the rolled tail path (debug / parity tests)
 //       bit1: start every chain from a fresh encoder's LMS state instead of loading d_lms
+//       bit2: never take the i16-packed fast path
+// d_stats (may be null): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
+//                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible
 hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out, const EncChain *d_chains,
-                         unsigned n_chains, int32_t *d_lms, unsigned flags, hipStream_t stream);
+                         unsigned n_chains, int32_t *d_lms, unsigned flags, unsigned long long *d_stats,
+                         hipStream_t stream);
 
 hipError_t launch_decode(const uint8_t *d_in, int16_t *d_out, const DecChain *d_chains, unsigned n_chains,
                          unsigned *d_mismatches, hipStream_t stream);

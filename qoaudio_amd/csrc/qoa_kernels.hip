@@ -231,7 +231,8 @@ __device__ __forceinline__ void run_slice_asm(unsigned tile_addr, int sf, const 
 // Hence: "penalty sum of a candidate < 1572^2" proves that all 20 steps of that candidate were exact, and that
 // its end state again satisfies what the next slice's first step needs.  A slice in which any candidate of the
 // wave fails the test is evaluated again by the 32-bit path from the same entry state (it never happens on
-// real audio or on the benchmark signals: profiles/r01f_redo_rate.txt).  After a 32-bit slice the state is
+// real audio or on the benchmark signals: qoa_encode_plan_stats() counts it, tests/test_gpu_parity.py checks the
+// reference's fixture and bench.py reports the workload's count).  After a 32-bit slice the state is
 // re-admitted by pk_try_pack(), which checks the ranges and the energy directly.
 // ------------------------------------------------------------------------------------------------
 struct PkLms {
@@ -308,7 +309,7 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
                    [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
                    [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
                    [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0xf0)
-                 : "vcc", "scc", "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
+                 : "vcc", "scc", "memory", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
                    "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
                    "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
                    "v121", "v122", "v123", "v124", "v125", "v126", "v127");
@@ -406,11 +407,14 @@ __device__ __forceinline__ void load_block_lane(const int16_t *__restrict__ p, u
 template <int CPW, int NCH>
 __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restrict__ pcm, uint8_t *__restrict__ out,
                                                          const EncChain *__restrict__ chains, unsigned n_chains,
-                                                         int32_t *__restrict__ lms_state, unsigned flags) {
+                                                         int32_t *__restrict__ lms_state, unsigned flags,
+                                                         unsigned long long *__restrict__ stats) {
     // sample tiles [wave][chain][kTileInts] + one slice of slack: the block loop prefetches one slice past its last
     __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts + 20];
     __shared__ __attribute__((aligned(256))) uint4 s_cand[4][CPW][16]; // candidate end states of the slice in flight
-    __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][32];   // [0,16): the block's winning slices, then dummies
+    // [0,16): the block's winning slices, [16,32): per-lane dummies; 48 entries = 384 B per chain so that the two
+    // chains a 64-lane ds_write_b64 serves per pass fall on disjoint banks
+    __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][48];
     const unsigned lane = threadIdx.x & 63u;
     const unsigned grp = lane >> 4;
     if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle
@@ -508,6 +512,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 typedef __attribute__((address_space(3))) int *lds_int;
                 j = run_block_pk((unsigned)(size_t)(lds_int)tile, cand_addr, outb_addr, outb_addr + 8u * (16u + (unsigned)sf),
                                  sf, kc, kBlockSlices, pk);
+                if (j < kBlockSlices && stats && sf == 0) atomicAdd(&stats[0], 1ull); // declined: see the slice loop
             }
         }
         for (; j < nj; j++) {
@@ -532,6 +537,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     continue;
                 }
                 // else: fall through and evaluate the slice again with 32-bit weights from the same entry state
+                if (stats && sf == 0) atomicAdd(&stats[0], 1ull); // (chain, slice) pairs the packed path declined
+            } else if (full && allow_packed && stats && sf == 0) {
+                atomicAdd(&stats[1], 1ull); // (chain, slice) pairs on the 32-bit path because a state was not admissible
             }
             if (packed) pk_unpack(pk, st);
 
@@ -894,14 +902,14 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 // ------------------------------------------------------------------------------------------------
 template <int CPW>
 static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
-                                    int32_t *lms, unsigned flags, hipStream_t stream) {
+                                    int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream) {
     constexpr unsigned kWavesPerBlock = 4;
     unsigned waves = (n + CPW - 1) / CPW;
     unsigned blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     dim3 g(blocks), b(64 * kWavesPerBlock);
 #define QOA_LAUNCH(N)                                                                                              \
     case N:                                                                                                        \
-        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N>), g, b, 0, stream, pcm, out, chains, n, lms, flags); \
+        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N>), g, b, 0, stream, pcm, out, chains, n, lms, flags, stats); \
         break;
     switch (nch) {
         QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
@@ -912,12 +920,12 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
 }
 
 hipError_t launch_encode(int cpw, int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
-                         int32_t *lms, unsigned flags, hipStream_t stream) {
+                         int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     switch (cpw) {
-    case 1: return launch_encode_nch<1>(nch, pcm, out, chains, n, lms, flags, stream);
-    case 2: return launch_encode_nch<2>(nch, pcm, out, chains, n, lms, flags, stream);
-    case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, stream);
+    case 1: return launch_encode_nch<1>(nch, pcm, out, chains, n, lms, flags, stats, stream);
+    case 2: return launch_encode_nch<2>(nch, pcm, out, chains, n, lms, flags, stats, stream);
+    case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, stats, stream);
     default: return hipErrorInvalidValue;
     }
 }

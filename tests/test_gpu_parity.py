@@ -407,6 +407,29 @@ def test_packed_fast_path_lane_by_lane(gpu, oracle):
     assert accepted >= 100 and declined >= 40 and penalised >= 5, (accepted, declined, penalised)
 
 
+def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
+    """The fast path's admission statistics on the reference's own fixture (real music, 2 x 239,414 slices): the
+    bytes are the oracle's either way, and the share of slices handed to the 32-bit path must stay negligible --
+    otherwise the kernel silently runs at half speed."""
+    from qoaudio_amd import batch
+    n = len(fixture_pcm) // 2
+    clips = [(0, 0, gpu.QoaDesc(2, 44100, n))]
+    pcm = torch.from_numpy(fixture_pcm).cuda()
+    outs = []
+    for flags in (batch.PLAN_DEFAULT, batch.PLAN_FORCE_32BIT_STEP):
+        plan = batch.EncodePlan(clips, flags)
+        out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
+        plan.run(pcm, out)
+        declined, unpacked = plan.stats()
+        outs.append(out.cpu().numpy().tobytes())
+        if flags == batch.PLAN_DEFAULT:
+            print(f"fixture: {declined} declined + {unpacked} unpacked of {2 * ((n + 19) // 20)} slices")
+            assert declined + unpacked <= 2 * ((n + 19) // 20) // 200
+        else:
+            assert (declined, unpacked) == (0, 0)
+    assert outs[0] == outs[1] == oracle.encode_all(fixture_pcm, 2, 44100, n)
+
+
 def test_rank_ties_resolved_like_the_reference(gpu, oracle):
     """Ties on the total rank must go to the candidate that is first in (first-sample rank, sf) order
     (strict '<' at src/lib.rs:587, stable insertion sort at :536).  Tied slices are found by searching small

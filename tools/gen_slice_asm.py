@@ -96,7 +96,7 @@ PK_OPERANDS = dict(w01="%[w01]", w23="%[w23]", pen="%[pen]", e="%[e]", acca="%[a
 # The block loop keeps everything that lives across slices in fixed registers (the statement's in/out operands are
 # register variables bound to v[84:87]): v[80:81] slice words, v[82:83] rank, v[84:87] packed state.
 PK_FIXED = dict(w01="v84", w23="v85", pen="v88", e="v[82:83]", acca="v89", accb="v90", aerr0="v79",
-                R=["v87", "v124", "v86", "v125"])
+                R=["v87", "v124", "v86", "v125"], alt=[f"v{r}" for r in range(67, 76)])
 
 
 def pk_step(i, N=PK_OPERANDS):
@@ -108,6 +108,8 @@ def pk_step(i, N=PK_OPERANDS):
     w01, w23, pen, e = N["w01"], N["w23"], N["pen"], N["e"]
     rc = RC[i % 2]
     P, Q, PR, T, U, SN, D, X, E = (f"v{r}" for r in (PK_P, PK_Q, PK_PR, PK_T, PK_U, PK_SN, PK_D, PK_X, PK_E))
+    if N.get("alt") and i % 2:  # second temporary set: lets the scheduler overlap neighbouring steps
+        P, Q, PR, T, U, SN, D, X, E = N["alt"]
     if i == 0:
         slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"
     else:
@@ -185,6 +187,104 @@ def pk_slice():
     return lines
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# List scheduler for a straight-line VALU region.  A lone wavefront issues an instruction that reads the result of
+# the instruction right before it ~0.33 cycle late (tools/ubench: dependent chain 4.46 vs independent 4.14 cycles
+# per instruction), so the region is re-ordered to put an independent instruction between producer and consumer
+# wherever the dependence graph allows, under the hard wait-state rules of gfx940/950:
+#   v_dot2 result -> read by anything but the same opcode's accumulator operand: 3 instructions between
+#   v_dot2 result -> overwritten by another VALU: 4 between;  packed (v_pk_*) result -> any VALU read: 1 between.
+import re
+
+_MOD = re.compile(r"\b(op_sel_hi|op_sel|row_ror|row_mask|bank_mask|offset):(\[[^\]]*\]|\S+)")
+
+
+def _regs(tok):
+    tok = tok.strip()
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return [f"v{k}" for k in range(int(m.group(1)), int(m.group(2)) + 1)]
+    if re.fullmatch(r"v\d+", tok) or tok == "vcc" or tok.startswith("%["):
+        return [tok]
+    return []  # immediates
+
+
+def _parse(line):
+    op, rest = line.split(None, 1)
+    ops = [t for t in _MOD.sub("", rest).split(",")]
+    regs = [_regs(t) for t in ops]
+    if op in ("v_mad_i64_i32", "v_mad_u64_u32"):
+        dst, src = regs[0] + regs[1], sum(regs[2:], [])
+    else:
+        dst, src = regs[0], sum(regs[1:], [])
+    acc = regs[-1] if op.startswith("v_dot2") else []      # the accumulator operand
+    return op, dst, src, acc
+
+
+def schedule(lines):
+    n = len(lines)
+    info = [_parse(l) for l in lines]
+    hard = [dict() for _ in range(n)]   # hard[j][i] = minimum distance j - i
+    soft = [dict() for _ in range(n)]
+    last_write, readers = {}, {}
+    for j, (op, dst, src, acc) in enumerate(info):
+        def need(i, h, sft):
+            hard[j][i] = max(hard[j].get(i, 0), h)
+            soft[j][i] = max(soft[j].get(i, 0), sft, h)
+        for r in src:
+            if r in last_write:
+                i = last_write[r]
+                pop = info[i][0]
+                if pop.startswith("v_dot2"):
+                    h = 1 if (op == pop and r in acc) else 4
+                elif pop.startswith("v_pk_"):
+                    h = 2
+                else:
+                    h = 1
+                need(i, h, 2)
+        for r in dst:
+            if r in last_write:
+                i = last_write[r]
+                need(i, 5 if info[i][0].startswith("v_dot2") and not op.startswith("v_dot2") else 1, 1)
+            for i in readers.get(r, []):
+                if i != j:
+                    need(i, 1, 1)
+        for r in src:
+            readers.setdefault(r, []).append(j)
+        for r in dst:
+            last_write[r] = j
+            readers[r] = []
+    succ = [[] for _ in range(n)]
+    for j in range(n):
+        for i in hard[j]:
+            succ[i].append(j)
+    prio = [0] * n
+    for i in range(n - 1, -1, -1):
+        prio[i] = 1 + max([prio[j] + soft[j][i] - 1 for j in succ[i]], default=0)
+    pos, order, t = {}, [], 0
+    npred = [len(hard[j]) for j in range(n)]
+    ready = {j for j in range(n) if npred[j] == 0}
+    while len(pos) < n:
+        ok = [j for j in ready if all(t - pos[i] >= d for i, d in hard[j].items())]
+        if not ok:
+            order.append("s_nop 0")
+            t += 1
+            continue
+        good = [j for j in ok if all(t - pos[i] >= d for i, d in soft[j].items())]
+        j = max(good or ok, key=lambda k: (prio[k], -k))
+        pos[j] = t
+        order.append(lines[j])
+        t += 1
+        ready.discard(j)
+        for k in succ[j]:
+            npred[k] -= 1
+            if npred[k] == 0:
+                ready.add(k)
+    back_to_back = sum(1 for j in range(n) for i, d in hard[j].items() if pos[j] - pos[i] == 1 and info[i][1] and
+                       set(info[i][1]) & set(info[j][2]))
+    return order, back_to_back
+
+
 def pk_block():
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
@@ -196,7 +296,7 @@ def pk_block():
     Exchange: every candidate parks its end state in its own 16-byte LDS slot before the election; afterwards all 16
     lanes read the winner's slot ((key2 & 0xf0) selects it: slots are 16 bytes, rows 256-byte aligned)."""
     N = PK_FIXED
-    K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"
+    K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"   # K1/M/K2 share the dot registers: see the s_nop below
     TCUR, OCUR = "v78", "v77"
     SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
     dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
@@ -212,14 +312,19 @@ def pk_block():
         "Lqoa_top_%=:",
         "s_waitcnt lgkmcnt(1)",                              # the winner's state (only a slice-word store may trail)
     ]
-    L += pk_prologue(N)
+    body = pk_prologue(N)
     for i in range(20):
-        L += pk_step(i, N)
-    E = f"v{PK_E}"
-    L += [
+        body += pk_step(i, N)
+    E = N["alt"][8]                                          # step 19 used the second temporary set
+    body += [
         f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
         f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
         f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
+    ]
+    body, b2b = schedule(body)
+    print(f"block body: {len(body)} instructions after scheduling, {b2b} consumers directly behind their producer")
+    L += body
+    L += [
         f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
         "s_cbranch_vccnz Lqoa_declined_%=",
         "ds_write_b128 %[cand], v[84:87]",
