@@ -269,3 +269,41 @@ def test_mul24_equals_wrapping_mul_inside_the_guard():
     sext24 = lambda v: ((v + 2 ** 23) % 2 ** 24) - 2 ** 23
     assert np.array_equal(wrap32(w * h), wrap32(sext24(w) * sext24(h)))
     assert np.array_equal(wrap32(w * w), wrap32(sext24(w) * sext24(w)))
+
+
+def test_generated_slice_asm_is_current():
+    """qoa_slice_asm.inc is generated (tools/gen_slice_asm.py) and committed: the committed text must be what the
+    generator produces now, and the scheduled block body must respect the wait-state rules it was built under."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_slice_asm", os.path.join(root, "tools", "gen_slice_asm.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    text, counts = g.render()
+    assert text == open(g.INC_PATH).read()
+    # independent re-check of the hazards on the final order of the block loop's straight-line body
+    body = [l for l in g.pk_block() if not l.endswith(":")]
+    last_write = {}
+    pos = 0
+    for line in body:
+        pos += 1
+        if line.split()[0].startswith(("s_", "ds_")):
+            if line.startswith("s_cbranch") or line.startswith("s_branch"):
+                last_write.clear()
+            if line.startswith("s_nop"):
+                pos += int(line.split()[1])  # s_nop N = N + 1 wait states
+            continue
+        op, dst, src, acc = g._parse(line)
+        for r in src:
+            if r in last_write:
+                wpos, wop = last_write[r]
+                if wop.startswith("v_dot2") and not (op == wop and r in acc):
+                    assert pos - wpos >= 4, line
+                if wop.startswith("v_pk_"):
+                    assert pos - wpos >= 2, line
+                if "_dpp" in op and r in g._regs(line.split()[2].rstrip(",")):
+                    assert pos - wpos >= 3, line
+        for r in dst:
+            if r in last_write and last_write[r][1].startswith("v_dot2") and not op.startswith("v_dot2"):
+                assert pos - last_write[r][0] >= 5, line
+            last_write[r] = (pos, op)

@@ -285,7 +285,7 @@ def schedule(lines):
     return order, back_to_back
 
 
-def pk_block():
+def pk_block(verbose=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -322,7 +322,8 @@ def pk_block():
         f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
     ]
     body, b2b = schedule(body)
-    print(f"block body: {len(body)} instructions after scheduling, {b2b} consumers directly behind their producer")
+    if verbose:
+        print(f"block body: {len(body)} instructions after scheduling, {b2b} consumers directly behind their producer")
     L += body
     L += [
         f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
@@ -375,10 +376,8 @@ def emit(name, lines):
     return f"#define {name} \\\n" + " \\\n".join(f'    "{l}\\n\\t"' for l in lines) + "\n"
 
 
-def main():
-    lines = []
-    for k in range(5):
-        lines.append(f"ds_read_b128 v[{SMP0 + 4 * k}:{SMP0 + 4 * k + 3}], %[tile] offset:{16 * k}")
+def render(verbose=False):
+    lines = sample_reads("%[tile]")
     for j in range(4):
         lines += [f"v_ashrrev_i32 v{S0 + j}, 31, %[h{j}]", f"v_or_b32 v{S0 + j}, 1, v{S0 + j}"]
     lines += ["v_mov_b64 %[e], 0", "v_mov_b32 %[pen], 0", "v_mov_b32 %[acca], 0", "v_mov_b32 %[accb], 0"]
@@ -387,18 +386,25 @@ def main():
             lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
         lines += step(i)
     pk = pk_slice()
-    blk = pk_block()
+    blk = pk_block(verbose)
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
            "// QOA_BLOCK_PK_ASM_TEXT: a loop over consecutive full slices on the packed path incl. winner election and\n"
-           "//   state exchange; fixed registers v76-v127, state in v[84:87].\n"
+           "//   state exchange; fixed registers v67-v127, state in v[84:87].\n"
            + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk) + "\n"
            + emit("QOA_BLOCK_PK_ASM_TEXT", blk))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
-    with open(path, "w") as f:
+    return out, (len(lines), len(pk), len(blk))
+
+
+INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
+
+
+def main():
+    out, counts = render(verbose=True)
+    with open(INC_PATH, "w") as f:
         f.write(out)
-    print(f"wrote {path}: {len(lines)} + {len(pk)} + {len(blk)} lines")
+    print(f"wrote {INC_PATH}: {counts[0]} + {counts[1]} + {counts[2]} lines")
 
 
 if __name__ == "__main__":
