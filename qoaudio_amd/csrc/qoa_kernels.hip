@@ -22,6 +22,7 @@
 // VALU instruction ISSUE (one wave per SIMD, ~4 cycles per instruction whatever it is), so the
 // candidate step is one hand-written 42-instruction block (cand_step); see DESIGN.md section 4.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -671,6 +672,73 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 // wave then copies the image out as 16-byte pieces of contiguous global memory.  The group stride in LDS
 // is an odd number of dwords, so the 2-byte scatter is bank-conflict free across frames.
 // ------------------------------------------------------------------------------------------------
+// K2 packed row.  A frame starts from i16 weights (they come from the header, src/lib.rs:276-281) and the history
+// is always i16, so the decoder can use the same i16-pair arithmetic as K1's fast path: 2 v_dot2_i32_i16 for the
+// prediction, 2 v_pk_mad_i16 for the update.  Exactness is a per-row guard here: one sample moves a weight by at
+// most |dequant| >> 4 <= mag3(sf) >> 4, so a row of 20 samples whose weights all satisfy
+// |w| + 20 * (mag3 >> 4) <= 32767 at its start cannot leave i16; the products are then exact and the i32
+// accumulation of v_dot2 is the reference's wrapping sum (src/lib.rs:799-805).  Rows that fail the guard (a hostile
+// stream can drive decoder weights anywhere) run the 32-bit step from the unpacked state, for the whole wave.
+// ------------------------------------------------------------------------------------------------
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+
+struct DecPk {
+    unsigned w01, w23;   // (w0, w1), (w2, w3)
+    unsigned pa, pm, pb; // history (h0, h1), (h1, h2), (h2, h3)
+    unsigned sa, sm, sb; // their +-1 pairs
+};
+
+__device__ __forceinline__ unsigned pk_signs(unsigned pair) {
+    const pk_i16 v = __builtin_bit_cast(pk_i16, pair);
+    const pk_i16 m = v >> (pk_i16){15, 15};
+    return __builtin_bit_cast(unsigned, m) | 0x00010001u;
+}
+
+__device__ __forceinline__ void dec_pack(const Lms &l, DecPk &p) {
+    auto pack = [](int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); };
+    p.w01 = pack(l.w0, l.w1); p.w23 = pack(l.w2, l.w3);
+    p.pa = pack(l.h0, l.h1); p.pm = pack(l.h1, l.h2); p.pb = pack(l.h2, l.h3);
+    p.sa = pk_signs(p.pa); p.sm = pk_signs(p.pm); p.sb = pk_signs(p.pb);
+}
+
+__device__ __forceinline__ void dec_unpack(const DecPk &p, Lms &l, int &s0, int &s1, int &s2, int &s3) {
+    l.w0 = (int)(p.w01 << 16) >> 16; l.w1 = (int)p.w01 >> 16;
+    l.w2 = (int)(p.w23 << 16) >> 16; l.w3 = (int)p.w23 >> 16;
+    l.h0 = (int)(p.pa << 16) >> 16; l.h1 = (int)p.pa >> 16;
+    l.h2 = (int)(p.pb << 16) >> 16; l.h3 = (int)p.pb >> 16;
+    sign_mults(l, s0, s1, s2, s3);
+}
+
+// |w_i| <= limit for the four packed weights (limit in 0..32767)
+__device__ __forceinline__ bool dec_weights_within(const DecPk &p, int limit) {
+    const pk_i16 a = __builtin_bit_cast(pk_i16, p.w01), b = __builtin_bit_cast(pk_i16, p.w23);
+    const pk_i16 hi = __builtin_elementwise_max(a, b), lo = __builtin_elementwise_min(a, b);
+    return hi.x <= limit && hi.y <= limit && lo.x >= -limit && lo.y >= -limit;
+}
+
+__device__ __forceinline__ bool fits_i16(int v) { return (unsigned)(v + 32768) < 65536u; }
+
+// One decoded sample on the packed state.  `mid` = (h1, h2): the pair the NEXT step uses as (h0, h1); the three
+// history pairs rotate by name in the unrolled caller.
+__device__ __forceinline__ int decode_step_pk(unsigned &w01, unsigned &w23, unsigned A, unsigned B, unsigned SA, unsigned SB,
+                                              unsigned &Bn, unsigned code, unsigned dq_lo, unsigned dq_hi) {
+    int p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w01), __builtin_bit_cast(pk_i16, A), 0, false);
+    p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w23), __builtin_bit_cast(pk_i16, B), p, false);
+    const int pred = p >> 13;
+    const int sneg = -(int)(code & 1u);
+    const unsigned sel = (code & 6u) * 0x0101u + 0x0c0c0100u;
+    const int mag = (int)__builtin_amdgcn_perm(dq_hi, dq_lo, sel);
+    const int deq = (mag ^ sneg) - sneg;
+    const int recon = med3(pred + deq, -32768, 32767);
+    const short delta = (short)(deq >> 4);
+    const pk_i16 d2 = {delta, delta};
+    w01 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SA) * d2 + __builtin_bit_cast(pk_i16, w01)));
+    w23 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SB) * d2 + __builtin_bit_cast(pk_i16, w23)));
+    Bn = __builtin_amdgcn_alignbit((unsigned)recon, B, 16); // (h3, recon)
+    return recon;
+}
+
+// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void decode_init_lms(const uint8_t *f, unsigned channel, Lms &l) {
     // 4 x i16 history, 4 x i16 weights, big-endian, sign-extended (src/lib.rs:271-281)
     const unsigned *s = (const unsigned *)(f + 8 + 16 * (size_t)channel);
@@ -786,6 +854,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     }
     int s0, s1, s2, s3;
     sign_mults(l, s0, s1, s2, s3);
+    DecPk pk;          // the chain's state while `packed` (l is then stale)
+    bool packed = true; // header values are i16
+    dec_pack(l, pk);
     // Slice loads are UNCONDITIONAL and clamped (a branch around a load makes hipcc wait for it at the join,
     // i.e. immediately): lanes without a frame, and rows past a frame's end, re-read a valid slice of lane 0's
     // frame -- every table entry has rows >= 1 -- and ignore it.
@@ -829,31 +900,58 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     }
     uint8_t *const dummy = scratch + lane * 16;
 
-    // The slice of the NEXT row is loaded while the current row decodes, and is byte-swapped (i.e. waited for)
-    // at the END of the current row -- before the flush stores of a chunk are issued -- so that no vmcnt wait
-    // for a load can ever sit behind those stores.
-    unsigned hi, lo;
-    {
-        const uint2 first = *(const uint2 *)sp;
-        hi = bswap32(first.x);
-        lo = bswap32(first.y);
-    }
-    uint2 dq = s_mags[hi >> 28];
+    // Slice loads.  vmcnt retires loads and stores in issue order, so a load issued AFTER a flush's stores cannot be
+    // waited for without waiting for those stores to reach memory first (a ~6 us stall per flush when the next
+    // row's slice was fetched one row ahead).  Hence the R slices of the NEXT group are requested together, right
+    // before the current group's flush stores, and row r of the next group waits with vmcnt(NP + R-1-r): its own
+    // load retired, the NP stores behind it still in flight.  hipcc cannot express that wait -- at the loop header
+    // it merges the pre-loop state (loads only) with the back edge (loads + stores) into a near-zero count -- so
+    // the loads and their waits are asm here, invisible to its vmcnt bookkeeping (the loop has no other loads).
+    auto load_row = [&](unsigned row) {
+        unsigned long long v;
+        const uint8_t *a = sp + (size_t)min(row, rows_ld - 1) * (8 * NCH);
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(a));
+        return v;
+    };
+    unsigned long long cur[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) cur[r] = load_row((unsigned)r);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // first group only: nothing is behind these loads yet
     for (unsigned row0 = 0; __builtin_amdgcn_ballot_w64(row0 < rows) != 0ull; row0 += R) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const unsigned row = row0 + r;
-            const uint2 nxt = *(const uint2 *)(sp + (size_t)min(row + 1, rows_ld - 1) * (8 * NCH)); // prefetch
+            // in flight, oldest first: loads r..R-1 of this group, then the previous flush's NP stores
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cur[r]) : "n"(NP + R - 1 - r));
+            const unsigned hi = bswap32((unsigned)cur[r]), lo = bswap32((unsigned)(cur[r] >> 32));
+            const uint2 dq = s_mags[hi >> 28];
             const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
+            const int dmax = (int)(dq.y >> 16) >> 4; // the largest weight step this row's scalefactor allows
+            const bool row_ok = packed && dec_weights_within(pk, 32767 - 20 * dmax);
+            if (__builtin_amdgcn_ballot_w64(!row_ok) == 0ull) {
+                // pair ring as in K1: B_i = (h[i-2], h[i-1]) lives in P[i % 4]; step i reads P[(i+2)%4] and P[i%4]
+                unsigned P[4] = {pk.pb, 0u, pk.pa, pk.pm}, S[4] = {pk.sb, 0u, pk.sa, pk.sm};
 #pragma unroll
-            for (int i = 0; i < 20; i++) {
-                int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
-                *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
+                for (int i = 0; i < 20; i++) {
+                    const int rec = decode_step_pk(pk.w01, pk.w23, P[(i + 2) % 4], P[i % 4], S[(i + 2) % 4], S[i % 4],
+                                                   P[(i + 1) % 4], (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
+                    S[(i + 1) % 4] = pk_signs(P[(i + 1) % 4]);
+                    *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
+                }
+                pk.pa = P[2]; pk.pm = P[3]; pk.pb = P[0]; // 20 % 4 == 0: the ring is back in place
+                pk.sa = S[2]; pk.sm = S[3]; pk.sb = S[0];
+            } else {
+                if (packed) dec_unpack(pk, l, s0, s1, s2, s3);
+#pragma unroll
+                for (int i = 0; i < 20; i++) {
+                    int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
+                    *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
+                }
+                packed = fits_i16(l.w0) && fits_i16(l.w1) && fits_i16(l.w2) && fits_i16(l.w3);
+                dec_pack(l, pk);
             }
-            hi = bswap32(nxt.x);
-            lo = bswap32(nxt.y);
-            dq = s_mags[hi >> 28];
         }
+#pragma unroll
+        for (int r = 0; r < R; r++) cur[r] = load_row(row0 + R + (unsigned)r); // next group: issued before the stores below
         // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step.
         // All LDS reads first (one wait), then NP unconditional stores.
         typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(2)));
