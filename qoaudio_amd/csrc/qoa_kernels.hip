@@ -718,24 +718,32 @@ __device__ __forceinline__ bool dec_weights_within(const DecPk &p, int limit) {
 
 __device__ __forceinline__ bool fits_i16(int v) { return (unsigned)(v + 32768) < 65536u; }
 
-// One decoded sample on the packed state.  `mid` = (h1, h2): the pair the NEXT step uses as (h0, h1); the three
-// history pairs rotate by name in the unrolled caller.
+// One decoded sample on the packed state.  `entry` comes from the LDS dequant table: low half = the dequantised
+// residual (src/lib.rs:309), high half = that value >> 4, the weight step of src/lib.rs:822 -- so the sample costs no
+// code-to-magnitude arithmetic at all, and the 20 lookups of a row are issued ahead of its serial chain.
+// B_i = (h[i-2], h[i-1]); the three live history pairs rotate by name in the unrolled caller.
 __device__ __forceinline__ int decode_step_pk(unsigned &w01, unsigned &w23, unsigned A, unsigned B, unsigned SA, unsigned SB,
-                                              unsigned &Bn, unsigned code, unsigned dq_lo, unsigned dq_hi) {
+                                              unsigned &Bn, unsigned entry) {
     int p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w01), __builtin_bit_cast(pk_i16, A), 0, false);
     p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w23), __builtin_bit_cast(pk_i16, B), p, false);
-    const int pred = p >> 13;
-    const int sneg = -(int)(code & 1u);
-    const unsigned sel = (code & 6u) * 0x0101u + 0x0c0c0100u;
-    const int mag = (int)__builtin_amdgcn_perm(dq_hi, dq_lo, sel);
-    const int deq = (mag ^ sneg) - sneg;
-    const int recon = med3(pred + deq, -32768, 32767);
-    const short delta = (short)(deq >> 4);
+    const int deq = (int)(short)(entry & 0xffffu);
+    const int recon = med3((p >> 13) + deq, -32768, 32767);
+    const short delta = (short)(entry >> 16);
     const pk_i16 d2 = {delta, delta};
     w01 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SA) * d2 + __builtin_bit_cast(pk_i16, w01)));
     w23 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SB) * d2 + __builtin_bit_cast(pk_i16, w23)));
     Bn = __builtin_amdgcn_alignbit((unsigned)recon, B, 16); // (h3, recon)
     return recon;
+}
+
+// LDS dequant table for the packed rows: [sf][code] = (dequant & 0xffff) | ((dequant >> 4) << 16)
+__device__ __forceinline__ void init_deq_table(unsigned (*s_deq)[8]) {
+    if (threadIdx.x < 128) {
+        const unsigned sf = threadIdx.x >> 3, code = threadIdx.x & 7u;
+        const int mag = c_mags[sf][code >> 1];
+        const int deq = (code & 1u) ? -mag : mag; // QOA_DEQUANT_TAB, src/lib.rs:847-864
+        s_deq[sf][code] = ((unsigned)deq & 0xffffu) | ((unsigned)(deq >> 4) << 16);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -833,7 +841,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     static_assert(GS % 16 == 0, "group image must be a whole number of 16-byte pieces");
     __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + 12];
     __shared__ uint2 s_mags[16];
-    init_mag_table(s_mags);
+    __shared__ unsigned s_deq[16][8];
+    init_deq_table(s_deq);
+    init_mag_table(s_mags); // (ends with the block barrier)
 
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned g = lane / NCH, c = lane % NCH;
@@ -923,9 +933,12 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
             // in flight, oldest first: loads r..R-1 of this group, then the previous flush's NP stores
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cur[r]) : "n"(NP + R - 1 - r));
             const unsigned hi = bswap32((unsigned)cur[r]), lo = bswap32((unsigned)(cur[r] >> 32));
-            const uint2 dq = s_mags[hi >> 28];
+            const unsigned *deq_row = s_deq[hi >> 28];
             const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
-            const int dmax = (int)(dq.y >> 16) >> 4; // the largest weight step this row's scalefactor allows
+            unsigned entry[20];
+#pragma unroll
+            for (int i = 0; i < 20; i++) entry[i] = deq_row[(unsigned)(slice >> (57 - 3 * i)) & 7u];
+            const int dmax = (int)(deq_row[6] >> 16); // the largest weight step this row's scalefactor allows
             const bool row_ok = packed && dec_weights_within(pk, 32767 - 20 * dmax);
             if (__builtin_amdgcn_ballot_w64(!row_ok) == 0ull) {
                 // pair ring as in K1: B_i = (h[i-2], h[i-1]) lives in P[i % 4]; step i reads P[(i+2)%4] and P[i%4]
@@ -933,7 +946,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 #pragma unroll
                 for (int i = 0; i < 20; i++) {
                     const int rec = decode_step_pk(pk.w01, pk.w23, P[(i + 2) % 4], P[i % 4], S[(i + 2) % 4], S[i % 4],
-                                                   P[(i + 1) % 4], (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
+                                                   P[(i + 1) % 4], entry[i]);
                     S[(i + 1) % 4] = pk_signs(P[(i + 1) % 4]);
                     *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
                 }
@@ -941,6 +954,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
                 pk.sa = S[2]; pk.sm = S[3]; pk.sb = S[0];
             } else {
                 if (packed) dec_unpack(pk, l, s0, s1, s2, s3);
+                const uint2 dq = s_mags[hi >> 28];
 #pragma unroll
                 for (int i = 0; i < 20; i++) {
                     int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
