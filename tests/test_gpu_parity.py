@@ -563,6 +563,41 @@ def test_decoder_frame_longer_than_its_slices(gpu, oracle):
     assert _same_items(gpu, oracle, bytes(hostile)) == 1 + 5120 * 2
 
 
+def test_batch_decode_mixes_packed_and_32bit_rows(gpu, oracle):
+    """K2 decodes a row on i16 pairs when every chain of the wave passes the per-row weight guard and on 32-bit
+    weights otherwise.  One plan, one wave: ordinary music, a frame whose weights are driven out of i16 for a while
+    (all-ones slices from extreme header weights) and then left alone, random garbage -- every stream must still
+    equal the oracle sample for sample."""
+    from qoaudio_amd import batch
+    r = np.random.default_rng(77)
+    music = oracle.encode_all(rng_pcm(9, 3 * 5120 * 2), 2, 44100, 3 * 5120)
+    hostile = bytearray(_crafted_stream(r, [(2, 44100, 5120, 256), (2, 44100, 5120, 256)], samples_field=10240))
+    hostile[16:48] = bytes([0x80, 0x00, 0x7f, 0xff] * 8)
+    body = 48 + 40 * 16
+    hostile[48:body] = b"\xff" * (body - 48)                      # 40 rows of sf 15 / code 7: weights leave i16
+    hostile[body:8 + 4136] = bytes(8 + 4136 - body)                 # then sf 0 / code 0: they stay where they are
+    garbage = _crafted_stream(r, [(2, 8000, 5120, 256)] * 3, samples_field=15360)
+    streams = [music, bytes(hostile), garbage, music]
+    offs_in, offs_out, a, b = [], [], 0, 0
+    for st in streams:
+        offs_in.append(a)
+        offs_out.append(b)
+        a += (len(st) + 7) // 8 * 8
+        b += 3 * 5120 * 2
+    plan = batch.DecodePlan.from_streams(streams, offs_in, offs_out)
+    assert plan.status == [0, 0, 0, 0]
+    buf = np.zeros(a, np.uint8)
+    for st, o in zip(streams, offs_in):
+        buf[o:o + len(st)] = np.frombuffer(st, np.uint8)
+    out = torch.zeros(b, dtype=torch.int16, device="cuda")
+    plan.run(torch.from_numpy(buf).cuda(), out)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    for st, o, n in zip(streams, offs_out, plan.samples_out):
+        _, _, want = oracle.decode_all(st)
+        assert n == len(want) and np.array_equal(host[o:o + n], want)
+
+
 def test_hypothesis_encode_decode_parity(gpu, oracle):
     """Property test (hypothesis): arbitrary small int16 signals, 1-8 channels: GPU bytes == oracle bytes and
     GPU decode == oracle decode (the reference's fuzz target, with parity on top)."""
