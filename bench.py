@@ -226,7 +226,7 @@ def main():
                             "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt())}
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        sample_clips = min(n_clips, 64)
+        sample_clips = min(n_clips, 96)
         host = pcm[:sample_clips].cpu().numpy()
         v1, n1, dt1, outs = cpu_baseline(host, ch, args.rate, args.cpu_seconds)
         he = out[:n1].cpu().numpy()
