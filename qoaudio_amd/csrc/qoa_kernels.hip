@@ -675,8 +675,8 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 // K2 packed row.  A frame starts from i16 weights (they come from the header, src/lib.rs:276-281) and the history
 // is always i16, so the decoder can use the same i16-pair arithmetic as K1's fast path: 2 v_dot2_i32_i16 for the
 // prediction, 2 v_pk_mad_i16 for the update.  Exactness is a per-row guard here: one sample moves a weight by at
-// most |dequant| >> 4 <= mag3(sf) >> 4, so a row of 20 samples whose weights all satisfy
-// |w| + 20 * (mag3 >> 4) <= 32767 at its start cannot leave i16; the products are then exact and the i32
+// most |dequant >> 4| <= ceil(mag3(sf) / 16), so a row of 20 samples whose weights all satisfy
+// |w| + 20 * ceil(mag3 / 16) <= 32767 at its start cannot leave i16; the products are then exact and the i32
 // accumulation of v_dot2 is the reference's wrapping sum (src/lib.rs:799-805).  Rows that fail the guard (a hostile
 // stream can drive decoder weights anywhere) run the 32-bit step from the unpacked state, for the whole wave.
 // ------------------------------------------------------------------------------------------------
@@ -839,7 +839,12 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     constexpr int PPG = GS / 16;                // 16-byte pieces per group image
     constexpr int NP = (FPW * PPG + 63) / 64;   // pieces per lane per flush
     static_assert(GS % 16 == 0, "group image must be a whole number of 16-byte pieces");
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + 12];
+    // When NCH does not divide 64 the last few lanes of a wave belong to no frame group (g == FPW).  They run the same
+    // code -- they serve flush pieces, ballots and bpermutes -- so they need an image slot of their own to scribble
+    // into: without it their row writes land in the NEXT wave's image (found by fuzzing multi-wave 3/5/6/7-channel
+    // batches; tests/test_gpu_parity.py::test_decode_channel_counts_that_do_not_divide_64).
+    constexpr int IMG_GROUPS = FPW + ((64 % NCH) ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][IMG_GROUPS * GSP + 12];
     __shared__ uint2 s_mags[16];
     __shared__ unsigned s_deq[16][8];
     init_deq_table(s_deq);
@@ -920,7 +925,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     auto load_row = [&](unsigned row) {
         unsigned long long v;
         const uint8_t *a = sp + (size_t)min(row, rows_ld - 1) * (8 * NCH);
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(a));
+        // "memory": hipcc must not move its own loads/stores across this one -- the counted waits below rely on
+        // exactly NP (or more) stores being issued between these loads and the next group's first wait
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(a) : "memory");
         return v;
     };
     unsigned long long cur[R];
@@ -931,14 +938,15 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // in flight, oldest first: loads r..R-1 of this group, then the previous flush's NP stores
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cur[r]) : "n"(NP + R - 1 - r));
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cur[r]) : "n"(NP + R - 1 - r) : "memory");
             const unsigned hi = bswap32((unsigned)cur[r]), lo = bswap32((unsigned)(cur[r] >> 32));
             const unsigned *deq_row = s_deq[hi >> 28];
             const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
             unsigned entry[20];
 #pragma unroll
             for (int i = 0; i < 20; i++) entry[i] = deq_row[(unsigned)(slice >> (57 - 3 * i)) & 7u];
-            const int dmax = (int)(deq_row[6] >> 16); // the largest weight step this row's scalefactor allows
+            // the largest weight step this row's scalefactor allows: |(-mag3) >> 4| = ceil(mag3 / 16), the code-7 entry
+            const int dmax = -((int)deq_row[7] >> 16);
             const bool row_ok = packed && dec_weights_within(pk, 32767 - 20 * dmax);
             if (__builtin_amdgcn_ballot_w64(!row_ok) == 0ull) {
                 // pair ring as in K1: B_i = (h[i-2], h[i-1]) lives in P[i % 4]; step i reads P[(i+2)%4] and P[i%4]

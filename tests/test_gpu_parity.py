@@ -598,6 +598,33 @@ def test_batch_decode_mixes_packed_and_32bit_rows(gpu, oracle):
         assert n == len(want) and np.array_equal(host[o:o + n], want)
 
 
+@pytest.mark.parametrize("channels", [3, 5, 6, 7])
+def test_decode_channel_counts_that_do_not_divide_64(gpu, oracle, channels):
+    """64 / channels frames share a wavefront and the remaining lanes idle; with more frames than one wavefront holds
+    the idle lanes of wave k used to write into wave k+1's LDS image (first channels of its first frame)."""
+    from qoaudio_amd import batch
+    fpw = 64 // channels
+    shapes = [(channels, 5120 * (2 * fpw + 1) + 77), (channels, 300), (channels, 5120 * fpw + 5)]
+    clips, parts, po, oo = [], [], 0, 0
+    for i, (ch, ns) in enumerate(shapes):
+        x = rng_pcm(700 + i, ns * ch, "mix")
+        parts.append(x)
+        clips.append((po, oo, gpu.QoaDesc(ch, 32000, ns)))
+        po += x.size
+        oo += gpu.encoded_size(ch, ns)
+    enc = np.concatenate([np.frombuffer(oracle.encode_all(x, d.channels, d.sample_rate, d.samples), np.uint8)
+                          for (_, _, d), x in zip(clips, parts)])
+    plan = batch.DecodePlan.from_clips(clips)
+    back = torch.zeros(po, dtype=torch.int16, device="cuda")
+    for _ in range(3):  # the overwrite was a race between wavefronts: give it a few chances
+        plan.run(torch.from_numpy(enc).cuda(), back)
+        torch.cuda.synchronize()
+        host = back.cpu().numpy()
+        for (p_, o_, d), x in zip(clips, parts):
+            _, _, want = oracle.decode_all(enc[o_:o_ + gpu.encoded_size(d.channels, d.samples)].tobytes())
+            assert np.array_equal(host[p_:p_ + len(want)], want), (d.channels, d.samples)
+
+
 def test_hypothesis_encode_decode_parity(gpu, oracle):
     """Property test (hypothesis): arbitrary small int16 signals, 1-8 channels: GPU bytes == oracle bytes and
     GPU decode == oracle decode (the reference's fuzz target, with parity on top)."""
