@@ -1,0 +1,100 @@
+"""Randomised parity against the oracle: ragged mixed-channel batches through K1 (both step forms) and K2, slices
+lane by lane around the packed path's admission window, hand-built hostile streams through the batch decoder.
+This is the test that found the idle-lane LDS overwrite in K2 (channel counts that do not divide 64).
+QOA_FUZZ_SCALE (default 1) multiplies the amount of work for a long run on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rng_pcm
+from test_gpu_parity import _crafted_stream, _gpu_slice
+
+pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("QOA_FUZZ_SCALE", "1"))
+KINDS = ["white", "loud", "mix", "square", "silence"]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_slices_lane_by_lane(gpu, oracle, seed):
+    r = np.random.default_rng(seed)
+    declined = 0
+    for _ in range(400 * SCALE):
+        amp = int(r.choice([100, 2000, 8000, 12000, 12290, 14000, 15800, 15950, 16100, 20000, 31000, 32767, 40000]))
+        w = [int(v) for v in r.integers(-amp, amp + 1, 4)]
+        if r.random() < 0.3:
+            w = [int(np.sign(v) or 1) * amp for v in w]
+        hist = [int(v) for v in r.integers(-32768, 32768, 4)]
+        if r.random() < 0.2:
+            hist = [int(r.choice([-32768, 32767, 0, -1])) for _ in range(4)]
+        smp = rng_pcm(int(r.integers(1 << 30)), 20, str(r.choice(KINDS)))
+        if r.random() < 0.3:
+            smp = (smp.astype(np.int32) // int(r.choice([1, 7, 100, 3000]))).astype(np.int16)
+        s, sf, (eh, ew), totals = oracle.encode_slice(hist, w, smp)
+        tot, aerr0, sl, es, win = _gpu_slice(hist + w, smp, 3)
+        assert tot == totals and win == sf and sl[sf] == s and list(es[sf]) == eh + ew, (hist, w, list(smp))
+        declined += _gpu_slice.declined
+    assert 0 < declined < 400 * SCALE
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_fuzz_ragged_batches_round_trip(gpu, oracle, seed):
+    from qoaudio_amd import batch
+    r = np.random.default_rng(seed)
+    for _ in range(2 * SCALE):
+        shapes = [(int(r.integers(1, 9)), int(r.integers(1, 30000))) for _ in range(int(r.integers(1, 40)))]
+        clips, parts, po, oo = [], [], 0, 0
+        for ch, ns in shapes:
+            x = rng_pcm(int(r.integers(1 << 30)), ns * ch, str(r.choice(KINDS)))
+            parts.append(x)
+            clips.append((po, oo, gpu.QoaDesc(ch, int(r.integers(1, 200000)), ns)))
+            po += x.size
+            oo += gpu.encoded_size(ch, ns)
+        pcm = torch.from_numpy(np.concatenate(parts)).cuda()
+        outs = []
+        for fl in (0, batch.PLAN_FORCE_32BIT_STEP):
+            out = torch.zeros(oo, dtype=torch.uint8, device="cuda")
+            batch.EncodePlan(clips, fl).run(pcm, out)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+        for (p_, o_, d), x in zip(clips, parts):
+            want = oracle.encode_all(x, d.channels, d.sample_rate, d.samples)
+            assert outs[0][o_:o_ + len(want)].tobytes() == want, shapes
+        back = torch.zeros_like(pcm)
+        batch.DecodePlan.from_clips(clips).run(torch.from_numpy(outs[0]).cuda(), back)
+        torch.cuda.synchronize()
+        hb = back.cpu().numpy()
+        for (p_, o_, d), x in zip(clips, parts):
+            _, _, want = oracle.decode_all(outs[0][o_:o_ + gpu.encoded_size(d.channels, d.samples)].tobytes())
+            assert np.array_equal(hb[p_:p_ + len(want)], want), shapes
+
+
+@pytest.mark.parametrize("seed", [6, 7])
+def test_fuzz_hostile_streams_batch_decode(gpu, oracle, seed):
+    from qoaudio_amd import batch
+    r = np.random.default_rng(seed)
+    for _ in range(4 * SCALE):
+        streams = []
+        for _ in range(int(r.integers(1, 12))):
+            k = int(r.integers(1, 4))
+            streams.append(_crafted_stream(r, [(int(r.integers(1, 9)), 8000, 5120, 256)] * k, samples_field=5120 * k))
+        wants = [oracle.decode_all(st)[2] for st in streams]
+        offs_in, offs_out, a, b = [], [], 0, 0
+        for st, w in zip(streams, wants):
+            offs_in.append(a)
+            offs_out.append(b)
+            a += (len(st) + 7) // 8 * 8
+            b += len(w)
+        plan = batch.DecodePlan.from_streams(streams, offs_in, offs_out)
+        buf = np.zeros(a, np.uint8)
+        for st, o in zip(streams, offs_in):
+            buf[o:o + len(st)] = np.frombuffer(st, np.uint8)
+        out = torch.zeros(b, dtype=torch.int16, device="cuda")
+        plan.run(torch.from_numpy(buf).cuda(), out)
+        torch.cuda.synchronize()
+        ho = out.cpu().numpy()
+        for w, o in zip(wants, offs_out):
+            assert np.array_equal(ho[o:o + len(w)], w)
+        assert np.array_equal(gpu.decode_all(streams[0]).samples, wants[0])
