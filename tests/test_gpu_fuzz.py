@@ -98,3 +98,24 @@ def test_fuzz_hostile_streams_batch_decode(gpu, oracle, seed):
         for w, o in zip(wants, offs_out):
             assert np.array_equal(ho[o:o + len(w)], w)
         assert np.array_equal(gpu.decode_all(streams[0]).samples, wants[0])
+
+
+@pytest.mark.parametrize("seed", [8, 9])
+def test_fuzz_streaming_encoder_frames_of_any_length(gpu, oracle, seed):
+    """encode_frame accepts 1..5120 sample-times per call (src/lib.rs:424-430); the LMS state is carried in device
+    memory from call to call.  Random channel counts and frame lengths, state compared after every call."""
+    r = np.random.default_rng(seed)
+    for _ in range(3 * SCALE):
+        ch = int(r.integers(1, 9))
+        lens = [int(r.choice([1, 19, 20, 21, 319, 320, 321, 5119, 5120, int(r.integers(1, 5121))])) for _ in range(int(r.integers(2, 7)))]
+        total = sum(lens)
+        enc = gpu.QoaEncoder(gpu.QoaDesc(ch, 48000, total))
+        ref = oracle.OracleEncoder(ch, 48000, total)
+        kind = str(r.choice(KINDS))
+        for n in lens:
+            x = rng_pcm(int(r.integers(1 << 30)), n * ch, kind)
+            fl, data = enc.encode_frame(x)
+            want, wfl = ref.encode_frame(x)
+            assert (fl, data) == (wfl, want), (ch, lens, n)
+            want_state = np.array([h + w for h, w in ref.lms_state()], dtype=np.int32)
+            assert np.array_equal(enc.lms_state(), want_state)
