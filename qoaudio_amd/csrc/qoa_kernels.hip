@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         const unsigned nj = min(nslices - k0, (unsigned)kBlockSlices);
         unsigned j = 0;
         {   // a block whose 16 slices are full in every chain of the wave, all chains packed: one statement does it
-            const bool whole = packed && !force_tail_path && (k0 + kBlockSlices) * 20u <= samples;
+            const bool whole = packed && !force_tail_path && (unsigned long long)(k0 + kBlockSlices) * 20u <= samples;
             if (__builtin_amdgcn_ballot_w64(!whole) == 0ull) {
                 typedef __attribute__((address_space(3))) int *lds_int;
                 j = run_block_pk((unsigned)(size_t)(lds_int)tile, cand_addr, outb_addr, outb_addr + 8u * (16u + (unsigned)sf),
