@@ -16,13 +16,14 @@
 // ~64 cycles of latency on the serial path 20x per slice).  The winner is the lexicographic minimum
 // of (total rank, first-sample rank, scalefactor) -- the closed form of the reference's rank-sorted
 // order with its two early exits -- found with two 32-bit row_ror DPP min-reductions, and its end
-// state is handed to all 16 lanes with ds_bpermute.
+// state reaches all 16 lanes through the chain's LDS slots (ds_bpermute on the per-slice fall-back paths).
 //
-// All arithmetic is 32-bit wrapping integer exactly as in the reference.  The kernel is bound by
-// VALU instruction ISSUE (one wave per SIMD, ~4 cycles per instruction whatever it is), so the
-// candidate step is one hand-written 42-instruction block (cand_step); see DESIGN.md section 4.
+// All arithmetic reproduces the reference's 32-bit wrapping integers exactly.  The kernel is bound by VALU
+// instruction ISSUE (one wave per SIMD, ~4 cycles per instruction whatever it is), so everything is about the
+// instruction count of the serial slice step: 35 instructions on i16-packed weights/history where that is provably
+// exact (the normal case), 41 on 32-bit weights otherwise; 16 full slices at a time run inside one generated asm
+// loop (qoa_slice_asm.inc, tools/gen_slice_asm.py).  See DESIGN.md section 4.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -76,7 +77,7 @@ struct CandResult {
 };
 
 // One candidate-sample step (src/lib.rs:566-584) as ONE hand-written instruction block:
-// 42 VALU instructions.  The kernel is issue-bound at one wave per SIMD (~4.7 cycles per instruction whatever
+// 41 VALU instructions.  The kernel is issue-bound at one wave per SIMD (~4.4 cycles per instruction whatever
 // it is, tools/ubench), so instruction COUNT is the cost; written in C++ the same step compiles to 43-44
 // instructions plus an s_nop after every one of its 6-7 inline-asm helpers (hipcc pads each asm boundary).
 //
@@ -190,7 +191,7 @@ __device__ __forceinline__ void run_slice_full(const int (&smp)[20], int sf, con
 }
 
 // The production path for a full slice: all 20 steps in ONE asm statement (text generated by
-// tools/gen_slice_asm.py from the same 42-instruction step as cand_step()).  Compared with 20 cand_step() statements
+// tools/gen_slice_asm.py from the same 41-instruction step as cand_step()).  Compared with 20 cand_step() statements
 // this drops the s_nop and s_waitcnt hipcc inserts at every asm boundary and the register copies around them;
 // the 20 samples are read from the LDS tile inside the block (`tile_addr` = LDS byte address of the slice).
 __device__ __forceinline__ void run_slice_asm(unsigned tile_addr, int sf, const StepConst &k, const Lms &entry,
