@@ -156,7 +156,7 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
  * the copies asynchronous).  The batch is cut along TIME: frames [j*F, (j+1)*F) of all clips are one kernel
  * launch (LMS state carried in device memory, as encode_frame does, src/lib.rs:414), overlapped with the
  * host->device copy of the next time slice and the device->host copy of the previous one.  chunk_frames = F,
- * 0 picks the default (16).  Synchronous: returns when h_out is complete. */
+ * 0 picks the default (8).  Synchronous: returns when h_out is complete. */
 int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
                           uint32_t chunk_frames);
 

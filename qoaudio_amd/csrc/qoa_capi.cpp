@@ -278,7 +278,7 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
         if (rc) return rc;
         max_frames = std::max<uint32_t>(max_frames, (clips[i].desc.samples + kFrameLen - 1) / kFrameLen);
     }
-    const uint32_t F = chunk_frames ? chunk_frames : 16; // 16 frames: 21.4 vs 20.3 G samples/s at 32 (config 3)
+    const uint32_t F = chunk_frames ? chunk_frames : 8; // config 3: 102.1 ms at 8 or 4 frames, 104.9 at 16, 111.3 at 32
     const uint32_t n_chunks = (max_frames + F - 1) / F;
 
     // device staging layout: per clip a PCM region of F frames and an encoded region of 8 + F frames, per buffer
