@@ -119,3 +119,28 @@ def test_fuzz_streaming_encoder_frames_of_any_length(gpu, oracle, seed):
             assert (fl, data) == (wfl, want), (ch, lens, n)
             want_state = np.array([h + w for h, w in ref.lms_state()], dtype=np.int32)
             assert np.array_equal(enc.lms_state(), want_state)
+
+
+@pytest.mark.parametrize("seed", [10, 11])
+def test_fuzz_decoder_iterator_on_damaged_streams(gpu, oracle, seed):
+    """QoaDecoder's item sequence (frame headers, samples, the error that ends it) on hand-built streams that are
+    truncated at random positions and have random bytes flipped in their headers -- fixed and streaming mode."""
+    from test_gpu_parity import _same_items
+    r = np.random.default_rng(seed)
+    for _ in range(12 * SCALE):
+        frames = []
+        for _ in range(int(r.integers(1, 4))):
+            ch = int(r.integers(1, 11))
+            nspc = int(r.choice([1, 20, 41, 5120, int(r.integers(1, 5121))]))
+            rows = (nspc + 19) // 20 if r.random() < 0.8 else int(r.integers(1, 257))
+            frames.append((ch, int(r.integers(1, 1 << 24)), nspc, rows))
+        fixed = r.random() < 0.6
+        if fixed:  # a fixed-mode file: every frame must repeat channels and rate (src/lib.rs:246-262)
+            frames = [(frames[0][0], frames[0][1], f[2], f[3]) for f in frames]
+        data = bytearray(_crafted_stream(r, frames, samples_field=sum(f[2] for f in frames) if fixed else 0))
+        if r.random() < 0.5:
+            del data[int(r.integers(0, len(data))):]
+        for _ in range(int(r.integers(0, 3))):
+            if len(data) > 16:
+                data[int(r.integers(0, 16))] ^= 1 << int(r.integers(0, 8))
+        _same_items(gpu, oracle, bytes(data))

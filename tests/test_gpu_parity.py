@@ -508,7 +508,13 @@ def _crafted_stream(rng, frames, samples_field=0):
 
 
 def _same_items(gpu, oracle, data):
-    ref = oracle.OracleDecoder(data)
+    try:
+        ref = oracle.OracleDecoder(data)
+    except oracle.OracleError as want:  # QoaDecoder::new itself fails (src/lib.rs:127-169): same error kind
+        with pytest.raises(gpu.DecodeError) as got:
+            gpu.QoaDecoder(data)
+        assert got.value.kind == want.args[0]
+        return 0
     dec = gpu.QoaDecoder(data)
     n = 0
     while True:
