@@ -166,12 +166,19 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
         int rc = validate_desc(&clips[i].desc);
         if (rc) return rc;
         if (clips[i].out_offset % 8 != 0) return fail_msg("qoa_clip.out_offset must be 8-byte aligned", QOA_ENCODE_IO_ERROR);
-        make_chains(clips[i], true, clips[i].desc.samples, per_nch[clips[i].desc.channels]);
         uint64_t n = (uint64_t)clips[i].desc.samples * clips[i].desc.channels;
         samples += n;
         pcm_bytes += n * 2;
         out_bytes += qoa_encoded_size(clips[i].desc.channels, clips[i].desc.samples);
     }
+    // Chains are serial and a wavefront runs as long as its longest chain, so clips are handed out longest first:
+    // wavefronts hold chains of similar length and the long ones start early.  (Which chains share a wavefront has no
+    // effect on the bytes.)  Channels of a clip stay adjacent: they write the same interleaved output lines.
+    std::vector<size_t> order(n_clips);
+    for (size_t i = 0; i < n_clips; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](size_t a, size_t b) { return clips[a].desc.samples > clips[b].desc.samples; });
+    for (size_t i : order) make_chains(clips[i], true, clips[i].desc.samples, per_nch[clips[i].desc.channels]);
     auto *plan = new (std::nothrow) qoa_encode_plan();
     if (!plan) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
     plan->pcm_bytes = pcm_bytes;
