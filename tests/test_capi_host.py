@@ -282,7 +282,11 @@ def test_generated_slice_asm_is_current():
     text, counts = g.render()
     assert text == open(g.INC_PATH).read()
     # independent re-check of the hazards on the final order of the block loop's straight-line body
-    body = [l for l in g.pk_block() if not l.endswith(":")]
+    for body in ([l for l in g.pk_block() if not l.endswith(":")], g.pk_slice()):
+        _check_wait_states(g, body)
+
+
+def _check_wait_states(g, body):
     last_write = {}
     pos = 0
     for line in body:
