@@ -159,7 +159,11 @@ def pk_step(i, N=PK_OPERANDS):
     return L
 
 
-def pk_prologue(N):
+def pk_zero(N):
+    return [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0"]
+
+
+def pk_prologue(N, zero=True):
     R, S = N["R"], PK_S
     return [
         f"v_alignbit_b32 {R[3]}, {R[0]}, {R[2]}, 16",        # B_(-1) = (h1, h2)
@@ -167,9 +171,7 @@ def pk_prologue(N):
         f"v_pk_ashrrev_i16 {S[3]}, 15, {R[3]} op_sel_hi:[0,1]",
         f"v_or_b32 {S[2]}, 0x10001, {S[2]}",
         f"v_or_b32 {S[3]}, 0x10001, {S[3]}",
-        f"v_mov_b64 {N['e']}, 0",
-        f"v_mov_b32 {N['pen']}, 0",
-    ]
+    ] + (pk_zero(N) if zero else [])
 
 
 def sample_reads(addr):
@@ -306,13 +308,13 @@ def pk_block(verbose=False):
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
         f"v_mov_b32 {ADDR}, %[cand]",
-    ] + sample_reads("%[tile]") + [
+    ] + sample_reads("%[tile]") + pk_zero(N) + [
         "s_mov_b32 %[done], 0",
         "s_waitcnt lgkmcnt(0)",
         "Lqoa_top_%=:",
         "s_waitcnt lgkmcnt(1)",                              # the winner's state (only a slice-word store may trail)
     ]
-    body = pk_prologue(N)
+    body = pk_prologue(N, zero=False)                        # rank and penalty sums are cleared in the election's gaps
     for i in range(20):
         body += pk_step(i, N)
     E = N["alt"][8]                                          # step 19 used the second temporary set
@@ -331,10 +333,9 @@ def pk_block(verbose=False):
         "ds_write_b128 %[cand], v[84:87]",
         f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
         f"v_lshlrev_b32 {K2}, 24, {ELO}",
-        f"v_mov_b32 {M}, {K1}",
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, {K2}",
         f"v_or_b32 {K2}, %[sf4], {K2}",
-        dpp(M, 8),
+        f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
         f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
         dpp(M, 4),
@@ -355,7 +356,7 @@ def pk_block(verbose=False):
         "s_add_u32 %[done], %[done], 1",
         "s_cmp_lt_u32 %[done], %[n]",
         dpp(K2, 2),
-        "s_nop 1",
+    ] + pk_zero(N) + [                                       # for the next slice; e and pen are dead by now
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, %[cand]",          # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
