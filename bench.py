@@ -194,8 +194,8 @@ def main():
         he = out[:2].cpu().numpy()
         ok = all(he[i].tobytes() == O.encode_all(hp[i].reshape(-1), ch, args.rate, samples) for i in range(2))
         result["bit_exact_vs_oracle"] = bool(ok)
-        declined, unpacked = plan.stats()  # K1's i16-packed fast path: slices it handed to the 32-bit path, all launches
-        result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked,
+        declined, unpacked, misses = plan.stats()  # K1's fast paths: slices handed to a slower form, all launches
+        result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked, "speculation_misses": misses,
                                  "slices_total": (args.warmup + args.steps) * n_clips * ch * ((samples + 19) // 20)}
         if world > 1 and gathered is not None:
             result["gathered_bytes"] = int(gathered.numel())

@@ -131,6 +131,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_DEFAULT 0u
 #define QOA_PLAN_FORCE_GENERIC_PATH 1u /* debug: run the rolled tail-slice path for every slice */
 #define QOA_PLAN_FORCE_32BIT_STEP 2u   /* debug: never take the i16-packed fast path (same bytes, tests compare) */
+#define QOA_PLAN_NO_SPECULATION 4u     /* debug: packed path always with its penalty arithmetic (same bytes) */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
 #define QOA_PLAN_CPW_2 (2u << 4)
 #define QOA_PLAN_CPW_4 (4u << 4)
@@ -144,12 +145,17 @@ int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint
 /* Enqueue the encode of the whole batch on `stream` (a hipStream_t, may be NULL).  d_pcm and
  * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
 int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);
-/* Diagnostics of the plan's runs so far (synchronises the device).  *declined_slices = (chain, slice) pairs for which
- * the kernel's i16-packed fast path could not prove its result exact and the 32-bit path evaluated the slice again;
- * *unpacked_slices = full slices that went straight to the 32-bit path because a chain's LMS state was outside the
- * packed path's range (|weight| > 32767 or weight energy too high).  Both are 0 on ordinary audio; neither affects
- * the bytes produced.  Either pointer may be null. */
-int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices);
+/* Diagnostics of the plan's runs so far (synchronises the device); none of this affects the bytes produced.
+ *   *declined_slices    (chain, slice) pairs for which the kernel's i16-packed path could not prove its result exact
+ *                       and the 32-bit path evaluated the slice again;
+ *   *unpacked_slices    full slices that went straight to the 32-bit path because a chain's LMS state was outside the
+ *                       packed path's range (|weight| > 32767 or weight energy too high);
+ *   *speculation_misses slices whose speculative evaluation (steps without penalty arithmetic) could not be proven and
+ *                       was repeated with it -- each miss also parks its wavefront on the full form for 4 blocks
+ *                       (64 slices).  Real music with strongly tonal passages shows a few per cent of these.
+ * The first two are 0 on ordinary audio.  Any pointer may be null. */
+int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices,
+                          uint64_t *speculation_misses);
 
 /* ---- batch encode on HOST-resident buffers: time-sliced pipeline ----
  * Semantically encode_all per clip (src/lib.rs:760-763) with h_pcm / h_out in host memory (pinned memory makes

@@ -16,6 +16,7 @@ from .api import DecodeError, EncodeError, QoaDesc, encoded_size
 PLAN_DEFAULT = 0
 PLAN_FORCE_GENERIC_PATH = 1
 PLAN_FORCE_32BIT_STEP = 2
+PLAN_NO_SPECULATION = 4
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 
 
@@ -71,14 +72,14 @@ class EncodePlan:
         if rc:
             raise EncodeError(rc)
 
-    def stats(self) -> Tuple[int, int]:
-        """(declined, unpacked): (chain, slice) pairs the kernel's i16-packed fast path handed to the 32-bit path,
-        summed over the plan's runs so far.  Diagnostics only (synchronises the device); 0, 0 on ordinary audio."""
-        a, b = C.c_uint64(0), C.c_uint64(0)
-        rc = _lib.lib().qoa_encode_plan_stats(self._h, C.byref(a), C.byref(b))
+    def stats(self) -> Tuple[int, int, int]:
+        """(declined, unpacked, speculation_misses): slices the kernel's fast paths handed to a slower form, summed over
+        the plan's runs so far (see qoa_encode_plan_stats).  Diagnostics only (synchronises the device)."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = _lib.lib().qoa_encode_plan_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
         if rc:
             raise EncodeError(rc)
-        return a.value, b.value
+        return a.value, b.value, c.value
 
 
 class DecodePlan:

@@ -9,9 +9,10 @@ namespace qoa {
 
 // flags bit0: run every slice through the rolled tail path (debug / parity tests)
 //       bit1: start every chain from a fresh encoder's LMS state instead of loading d_lms
-//       bit2: never take the i16-packed fast path
-// d_stats (may be null): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
-//                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible
+//       bit2: never take the i16-packed fast path      bit3: no speculative (penalty-free) steps
+// d_stats (may be null, 3 x u64): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
+//                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible,
+//                        [2] += (chain, slice) pairs whose speculative evaluation was repeated by the full form
 hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out, const EncChain *d_chains,
                          unsigned n_chains, int32_t *d_lms, unsigned flags, unsigned long long *d_stats,
                          hipStream_t stream);

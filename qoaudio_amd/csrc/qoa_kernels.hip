@@ -319,6 +319,49 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
     return done;
 }
 
+// The speculative form of run_block_pk (QOA_BLOCK_SPEC_ASM_TEXT): steps without any penalty arithmetic (30 instructions,
+// 33 at the five steps that sample the weight energy), proven after each slice by two tests on the sampled maximum --
+// limq: every candidate stayed inside the i16 window (so all 64 ranks are exact err^2 sums); winq: the WINNER's penalty
+// was zero at every step, hence its rank is its true rank while every other candidate's true rank is >= its computed
+// one, and the reference's winner is this winner.  Margins for the three unsampled steps are folded into limq / winq
+// (spec_limits).  A slice that fails either test ends the call (done < n) with its entry state restored; the caller runs
+// it through the full form.  `pp` = byte distance between the two candidate-slot buffers.
+__device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
+                                                   int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk) {
+    register unsigned w01 asm("v84") = pk.w01;
+    register unsigned w23 asm("v85") = pk.w23;
+    register unsigned pa asm("v86") = pk.pa;
+    register unsigned pb asm("v87") = pk.pb;
+    unsigned done;
+    asm volatile(QOA_BLOCK_SPEC_ASM_TEXT
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
+                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
+                   [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
+                   [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),
+                   [mf0] "s"(0xf0), [pp] "s"(pp)
+                 : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                   "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+                   "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                   "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+                   "v124", "v125", "v126", "v127");
+    pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
+    return done;
+}
+
+// Thresholds of the speculative form for scalefactor sf, in units of (weight energy - (0x8ff << 18)) as the steps sample
+// it.  One step changes the energy S = sum w^2 by at most 2 d sum|w| + 4 d^2 <= 4 d sqrt(S) + 4 d^2 with
+// d = ceil(mag3(sf) / 16) the largest weight step (sum|w| <= 2 sqrt(S)).  Three steps go unsampled after each sample:
+//   limq: S + 3 G < kPkEnergyLimit, G = 4 d 31872 + 4 d^2  -> S stays below the limit (sqrt < 31872) until the next sample,
+//         which is run_slice_pk's exactness invariant;
+//   winq: S + 3 G' < 0x900 << 18, G' = 4 d 24576 + 4 d^2    -> the penalty (S >> 18) - 0x8ff is <= 0 at every step.
+__device__ __forceinline__ void spec_limits(int sf, int &limq, int &winq) {
+    const long long d = (c_mags[sf][3] + 15) >> 4;
+    const long long c = 0x8ffll << 18;
+    limq = (int)(kPkEnergyLimit - 3 * (4 * d * 31872 + 4 * d * d) - c);
+    winq = (int)((0x900ll << 18) - 3 * (4 * d * 24576 + 4 * d * d) - c);
+}
+
 // Any slice length 1..20 (the last slice of a clip).  Rolled loop; the sample window is shifted through
 // registers so nothing is runtime-indexed (a runtime index would put the array in scratch).  Codes are
 // placed at their final bit positions, which is the reference's tail shift (src/lib.rs:485-487) for free.
@@ -391,6 +434,7 @@ __device__ __forceinline__ unsigned bswap32(unsigned v) { return __builtin_bswap
 // headers / LMS dumps are written at block tops too.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlockSlices = 16;
+constexpr unsigned kSpecCooldownBlocks = 4; // blocks on the full step form after a speculation miss (misses cluster)
 constexpr int kTileInts = kBlockSlices * 20 + 4; // +16 B: the 4 chain tiles of a wave start on different banks
 
 template <int NCH>
@@ -413,7 +457,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                                                          unsigned long long *__restrict__ stats) {
     // sample tiles [wave][chain][kTileInts] + one slice of slack: the block loop prefetches one slice past its last
     __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts + 20];
-    __shared__ __attribute__((aligned(256))) uint4 s_cand[4][CPW][16]; // candidate end states of the slice in flight
+    // candidate end states of the slice in flight; two buffers: the speculative loop alternates between them so that
+    // a slice's entry state (the previous winner's slot) survives until the slice is known to be final
+    __shared__ __attribute__((aligned(256))) uint4 s_cand[2][4][CPW][16];
     // [0,16): the block's winning slices, [16,32): per-lane dummies; 48 entries = 384 B per chain so that the two
     // chains a 64-lane ds_write_b64 serves per pass fall on disjoint banks
     __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][48];
@@ -429,7 +475,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     int *tile = s_smp + (wave_in_block * CPW + grp) * kTileInts;
     uint2 *out_tile = s_out[wave_in_block][grp];
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[wave_in_block][grp][sf];
+    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[0][wave_in_block][grp][sf];
+    constexpr unsigned kCandBufBytes = 4u * CPW * 16u * sizeof(uint4);
     const unsigned outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
 
     const EncChain ch = chains[chain_id];
@@ -446,6 +493,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     kc.hi = 32767;
     const bool force_tail_path = (flags & 1u) != 0;
     const bool allow_packed = (flags & 4u) == 0; // bit 2: 32-bit step only (tests compare the two)
+    const bool allow_spec = (flags & 8u) == 0;   // bit 3: no speculative (penalty-free) steps
+    int limq, winq;
+    spec_limits(sf, limq, winq);
+    unsigned spec_cooldown = 0; // blocks left on the full form after a speculation miss (wave-uniform)
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -512,10 +563,21 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             const bool whole = packed && !force_tail_path && (unsigned long long)(k0 + kBlockSlices) * 20u <= samples;
             if (__builtin_amdgcn_ballot_w64(!whole) == 0ull) {
                 typedef __attribute__((address_space(3))) int *lds_int;
-                j = run_block_pk((unsigned)(size_t)(lds_int)tile, cand_addr, outb_addr, outb_addr + 8u * (16u + (unsigned)sf),
-                                 sf, kc, kBlockSlices, pk);
-                if (j < kBlockSlices && stats && sf == 0) atomicAdd(&stats[0], 1ull); // declined: see the slice loop
+                const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
+                if (allow_spec && spec_cooldown == 0) {
+                    j = run_block_spec(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk);
+                    if (j < kBlockSlices) { // slice j could not be proven: the full form takes over, here and for a while
+                        spec_cooldown = kSpecCooldownBlocks + 1;
+                        if (stats && sf == 0) atomicAdd(&stats[2], 1ull);
+                    }
+                }
+                if (j < kBlockSlices) {
+                    const unsigned j0 = j;
+                    j += run_block_pk(tile0 + 80u * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
+                    if (j < kBlockSlices && stats && sf == 0) atomicAdd(&stats[0], 1ull); // declined: see the slice loop
+                }
             }
+            if (spec_cooldown) spec_cooldown--;
         }
         for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);

@@ -282,7 +282,8 @@ def test_generated_slice_asm_is_current():
     text, counts = g.render()
     assert text == open(g.INC_PATH).read()
     # independent re-check of the hazards on the final order of the block loop's straight-line body
-    for body in ([l for l in g.pk_block() if not l.endswith(":")], g.pk_slice()):
+    for body in ([l for l in g.pk_block() if not l.endswith(":")], g.pk_slice(),
+                 [l for l in g.pk_block(spec=True) if not l.endswith(":")]):
         _check_wait_states(g, body)
 
 

@@ -129,13 +129,14 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32"])
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "nospec"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
     fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
-          "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP}[flags]
+          "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP,
+          "nospec": batch.PLAN_NO_SPECULATION}[flags]
     shapes = [(2, 5300), (1, 41), (2, 20), (3, 999), (2, 12000), (1, 6000), (8, 333), (2, 1), (1, 5120), (2, 5121),
               (5, 777), (2, 640), (1, 10240), (2, 319)]
     clips, pcm_parts, pcm_off, out_off = [], [], 0, 0
@@ -416,18 +417,22 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     clips = [(0, 0, gpu.QoaDesc(2, 44100, n))]
     pcm = torch.from_numpy(fixture_pcm).cuda()
     outs = []
-    for flags in (batch.PLAN_DEFAULT, batch.PLAN_FORCE_32BIT_STEP):
+    for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP):
         plan = batch.EncodePlan(clips, flags)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
-        declined, unpacked = plan.stats()
+        declined, unpacked, misses = plan.stats()
         outs.append(out.cpu().numpy().tobytes())
         if flags == batch.PLAN_DEFAULT:
-            print(f"fixture: {declined} declined + {unpacked} unpacked of {2 * ((n + 19) // 20)} slices")
+            print(f"fixture: {declined} declined + {unpacked} unpacked, {misses} speculation misses "
+                  f"of {2 * ((n + 19) // 20)} slices")
             assert declined + unpacked <= 2 * ((n + 19) // 20) // 200
+            assert 0 < misses <= 2 * ((n + 19) // 20) // 20  # tonal passages: a few per cent, never the bulk
+        elif flags == batch.PLAN_NO_SPECULATION:
+            assert misses == 0 and declined + unpacked <= 2 * ((n + 19) // 20) // 200
         else:
-            assert (declined, unpacked) == (0, 0)
-    assert outs[0] == outs[1] == oracle.encode_all(fixture_pcm, 2, 44100, n)
+            assert (declined, unpacked, misses) == (0, 0, 0)
+    assert outs[0] == outs[1] == outs[2] == oracle.encode_all(fixture_pcm, 2, 44100, n)
 
 
 def test_rank_ties_resolved_like_the_reference(gpu, oracle):

@@ -96,10 +96,10 @@ PK_OPERANDS = dict(w01="%[w01]", w23="%[w23]", pen="%[pen]", e="%[e]", acca="%[a
 # The block loop keeps everything that lives across slices in fixed registers (the statement's in/out operands are
 # register variables bound to v[84:87]): v[80:81] slice words, v[82:83] rank, v[84:87] packed state.
 PK_FIXED = dict(w01="v84", w23="v85", pen="v88", e="v[82:83]", acca="v89", accb="v90", aerr0="v79",
-                R=["v87", "v124", "v86", "v125"], alt=[f"v{r}" for r in range(67, 76)])
+                R=["v87", "v124", "v86", "v125"], alt=[f"v{r}" for r in range(67, 76)], qm="v66")
 
 
-def pk_step(i, N=PK_OPERANDS):
+def pk_step(i, N=PK_OPERANDS, spec=False):
     R, S, RC = N["R"], PK_S, PK_RC
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
@@ -115,22 +115,27 @@ def pk_step(i, N=PK_OPERANDS):
     else:
         slot_a = f"v_sub_u32 {E}, v{SMP0 + i - 1}, {RC[(i - 1) % 2]}"      # err of the previous step
         slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}"
+    # Speculative form (spec): no penalty arithmetic at all; the weight energy is only sampled, at every 4th step, into a
+    # running maximum that the block loop tests after the slice (see pk_block).
+    pen_full = not spec
+    check = spec and i % 4 == 0
     L = [
         f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
-        f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]",       # sum w^2 - (0x8ff << 18)
+        f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]" if pen_full or check else None,   # sum w^2 - (0x8ff << 18)
         f"v_dot2_i32_i16 {P}, {w23}, {B}, {P}",
-        f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}",
+        f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}" if pen_full or check else None,
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",   # the inline 15 has no high half to select
         slot_a,
         f"v_or_b32 {SB}, 0x10001, {SB}",                    # (+-1, +-1) for B_n
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
-        f"v_ashrrev_i32 {X}, 18, {Q}",
+        f"v_ashrrev_i32 {X}, 18, {Q}" if pen_full else None,
         f"v_sub_u32 {T}, {smp}, {PR}",                      # residual
         slot_b,
-        f"v_max_i32 {X}, 0, {X}",                           # penalty
+        f"v_max_i32 {X}, 0, {X}" if pen_full else None,     # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1",
-        f"v_mad_i32_i24 {pen}, {X}, {X}, {pen}",
+        f"v_mad_i32_i24 {pen}, {X}, {X}, {pen}" if pen_full else None,
+        (f"v_mov_b32 {N['qm']}, {Q}" if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
         f"v_ashrrev_i32 {U}, 16, {U}",
         f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
         f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled
@@ -152,7 +157,8 @@ def pk_step(i, N=PK_OPERANDS):
         f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
         f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
     ]
-    assert len(L) == 35
+    L = [l for l in L if l is not None]
+    assert len(L) == (35 if not spec else 33 if check else 30)
     if i == 1:  # |err| of the first sample, right after slot_a produced it
         k = L.index(slot_a) + 1
         L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
@@ -287,7 +293,7 @@ def schedule(lines):
     return order, back_to_back
 
 
-def pk_block(verbose=False):
+def pk_block(verbose=False, spec=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -296,19 +302,32 @@ def pk_block(verbose=False):
     wait states a DPP read needs after a VALU write of its source are filled with the slice-word packing, the loop
     counter and the NEXT slice's five sample reads, so the reads' latency is off the serial chain too.
     Exchange: every candidate parks its end state in its own 16-byte LDS slot before the election; afterwards all 16
-    lanes read the winner's slot ((key2 & 0xf0) selects it: slots are 16 bytes, rows 256-byte aligned)."""
+    lanes read the winner's slot ((key2 & 0xf0) selects it: slots are 16 bytes, rows 256-byte aligned).
+
+    spec=True is the speculative form: the steps carry no penalty arithmetic (pk_step); instead every candidate's
+    weight energy minus 0x8ff << 18, sampled at steps 0, 4, .. 16, is kept as a running maximum QM and tested twice:
+      all 64 candidates  QM < %[limq]   (arithmetic provably exact: the energy cannot have left the i16 window in the
+                                         three unsampled steps either) -- before the election, as the full form does;
+      the winner         QM < %[winq]   (its penalty was zero at all 20 steps, so its rank is its true rank, and every
+                                         other candidate's true rank is at least its computed one: same winner).
+    The second test comes after the election, when this slice's candidates already sit in the LDS slots; the slots are
+    therefore double-buffered (%[pp] = byte distance) so that the entry state is still there for a late exit."""
     N = PK_FIXED
-    K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"   # K1/M/K2 share the dot registers: see the s_nop below
+    K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"   # K1/M/K2 share the dot registers (long dead by now)
     TCUR, OCUR = "v78", "v77"
     SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
+    CANDC, PADDR, THR, QM = "v65", "v64", "v119", N["qm"]
+    cand = CANDC if spec else "%[cand]"
+    prev = PADDR if spec else ADDR
     dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
+    zero = [f"v_mov_b64 {N['e']}, 0"] + ([] if spec else [f"v_mov_b32 {N['pen']}, 0"])
     L = []
     L += [
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an early exit restores
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
-        f"v_mov_b32 {ADDR}, %[cand]",
-    ] + sample_reads("%[tile]") + pk_zero(N) + [
+        f"v_mov_b32 {prev}, %[cand]",
+    ] + ([f"v_mov_b32 {CANDC}, %[cand]"] if spec else []) + sample_reads("%[tile]") + zero + [
         "s_mov_b32 %[done], 0",
         "s_waitcnt lgkmcnt(0)",
         "Lqoa_top_%=:",
@@ -316,21 +335,22 @@ def pk_block(verbose=False):
     ]
     body = pk_prologue(N, zero=False)                        # rank and penalty sums are cleared in the election's gaps
     for i in range(20):
-        body += pk_step(i, N)
+        body += pk_step(i, N, spec)
     E = N["alt"][8]                                          # step 19 used the second temporary set
     body += [
         f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
         f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
-        f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
-    ]
+    ] + ([] if spec else [f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}"])   # total rank = sum err^2 + sum penalty^2
     body, b2b = schedule(body)
     if verbose:
-        print(f"block body: {len(body)} instructions after scheduling, {b2b} consumers directly behind their producer")
+        print(f"block body{' (speculative)' if spec else ''}: {len(body)} instructions after scheduling, "
+              f"{b2b} consumers directly behind their producer")
     L += body
     L += [
-        f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
+        f"v_cmp_ge_i32 vcc, {QM}, %[limq]" if spec else f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
         "s_cbranch_vccnz Lqoa_declined_%=",
-        "ds_write_b128 %[cand], v[84:87]",
+    ] + ([f"v_xor_b32 {CANDC}, %[pp], {CANDC}"] if spec else []) + [   # the other slot buffer: the entry state stays put
+        f"ds_write_b128 {cand}, v[84:87]",
         f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
         f"v_lshlrev_b32 {K2}, 24, {ELO}",
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, {K2}",
@@ -356,17 +376,24 @@ def pk_block(verbose=False):
         "s_add_u32 %[done], %[done], 1",
         "s_cmp_lt_u32 %[done], %[n]",
         dpp(K2, 2),
-    ] + pk_zero(N) + [                                       # for the next slice; e and pen are dead by now
+    ] + (zero if not spec else zero + ["s_nop 0"]) + [       # for the next slice; e (and pen) are dead by now
         dpp(K2, 1),
-        f"v_bfi_b32 {ADDR}, %[mf0], {K2}, %[cand]",          # the winner's slot
+        f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {cand}",           # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
-        f"v_cmp_eq_u32 vcc, {ADDR}, %[cand]",
+        f"v_cmp_eq_u32 vcc, {ADDR}, {cand}",
         f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
+    ] + ([f"v_cndmask_b32 {THR}, %[limq], %[winq], vcc"] if spec else []) + [   # non-winners: the test they already passed
         f"ds_write_b64 {OADDR}, v[80:81]",
+    ] + ([
+        f"v_cmp_ge_i32 vcc, {QM}, {THR}",                    # can only fire in the winner's lane
+        "s_cbranch_vccnz Lqoa_late_%=",
+        f"v_mov_b32 {PADDR}, {ADDR}",                        # this slice is final: its winner's slot holds the next entry state
+    ] if spec else []) + [
         "s_cbranch_scc1 Lqoa_top_%=",
         "s_branch Lqoa_end_%=",
+    ] + (["Lqoa_late_%=:", "s_sub_u32 %[done], %[done], 1"] if spec else []) + [
         "Lqoa_declined_%=:",
-        f"ds_read_b128 v[84:87], {ADDR}",                    # entry state of the declined slice
+        f"ds_read_b128 v[84:87], {prev}",                    # entry state of the declined slice
         "Lqoa_end_%=:",
         "s_waitcnt lgkmcnt(0)",
     ]
@@ -388,14 +415,17 @@ def render(verbose=False):
         lines += step(i)
     pk = pk_slice()
     blk = pk_block(verbose)
+    blk_spec = pk_block(verbose, spec=True)
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
            "// QOA_BLOCK_PK_ASM_TEXT: a loop over consecutive full slices on the packed path incl. winner election and\n"
            "//   state exchange; fixed registers v67-v127, state in v[84:87].\n"
+           "// QOA_BLOCK_SPEC_ASM_TEXT: the same loop with speculative steps (30/33 instructions, no penalty arithmetic) and\n"
+           "//   the two energy tests that prove a slice's result; fixed registers v64-v127.\n"
            + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk) + "\n"
-           + emit("QOA_BLOCK_PK_ASM_TEXT", blk))
-    return out, (len(lines), len(pk), len(blk))
+           + emit("QOA_BLOCK_PK_ASM_TEXT", blk) + "\n" + emit("QOA_BLOCK_SPEC_ASM_TEXT", blk_spec))
+    return out, (len(lines), len(pk), len(blk), len(blk_spec))
 
 
 INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
@@ -405,7 +435,7 @@ def main():
     out, counts = render(verbose=True)
     with open(INC_PATH, "w") as f:
         f.write(out)
-    print(f"wrote {INC_PATH}: {counts[0]} + {counts[1]} + {counts[2]} lines")
+    print(f"wrote {INC_PATH}: {counts[0]} + {counts[1]} + {counts[2]} + {counts[3]} lines")
 
 
 if __name__ == "__main__":
