@@ -38,11 +38,11 @@ def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
 
 def valu_issue(n_chains: int, samples: int, kernel_ms: float):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
-    Instruction count per slice is the PMC-measured 744 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4,
-    profiles/r01f_pmc_summary.txt); a lone wavefront per SIMD can issue at most one instruction per 4 cycles."""
+    Instruction count per slice is the PMC-measured 660 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4,
+    profiles/r01i_pmc_summary.txt); a lone wavefront per SIMD can issue at most one instruction per 4 cycles."""
     waves = (n_chains + 3) // 4
     slices = (samples + 19) // 20
-    achieved = 744.0 * slices * waves / (kernel_ms * 1e-3)
+    achieved = 660.0 * slices * waves / (kernel_ms * 1e-3)
     peak = 1024 * 2.4e9 / 4.0
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s",
             "frac": achieved / peak, "wavefronts": waves}
@@ -182,7 +182,7 @@ def main():
                      "traffic": pmc_traffic("encode", n_clips, ch, args.frames), "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md",
-                     # the bound that actually governs K1 (profiles/r01f_pmc_summary.txt): 744 VALU wave-instructions
+                     # the bound that actually governs K1 (profiles/r01i_pmc_summary.txt): 660 VALU wave-instructions
                      # per slice per wavefront, one per 4 cycles per SIMD at 2.4 GHz on 1024 SIMDs
                      "valu_issue": valu_issue(n_clips * ch, samples, k_avg_ms)},
     }
