@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Generates qoaudio_amd/csrc/qoa_slice_asm.inc: the full 20-step candidate evaluation of one slice as ONE
-inline-asm text (run: python tools/gen_slice_asm.py).  The step is the same 41-instruction sequence as
-cand_step() in qoa_kernels.hip; writing all 20 steps in one statement removes the s_nop / s_waitcnt pads hipcc puts
-at every asm-statement boundary and lets the history / sign rings rotate by register NAME (20 % 4 == 0, so
-after the slice every ring register again holds the element it started with).
+"""Generates qoaudio_amd/csrc/qoa_slice_asm.inc (run: python tools/gen_slice_asm.py): K1's slice evaluation as inline-asm
+texts.  Writing whole slices -- and whole 16-slice blocks -- as ONE statement removes the s_nop / s_waitcnt pads hipcc
+puts at every asm-statement boundary, lets the history / sign rings rotate by register NAME (20 % 4 == 0: after a slice
+every ring register again holds the element it started with) and puts every wait state under the author's control.
 
-Scratch VGPRs (declared as clobbers): v[96:115] the 20 samples, v[116:117] / v[118:119] the two dot-product
-pairs, v120-v123 temporaries, v124-v127 the +-1 sign ring.
+  QOA_SLICE_ASM_TEXT       20 x step(): 41 instructions, full 32-bit weights (the same sequence as cand_step() in
+                           qoa_kernels.hip).  Scratch: v[96:115] samples, v[116:119] dot-product pairs, v120-v123
+                           temporaries, v124-v127 the +-1 sign ring.
+  QOA_SLICE_PK_ASM_TEXT    20 x pk_step(): 35 instructions on i16-packed weights / history, one slice.
+  QOA_BLOCK_PK_ASM_TEXT    pk_block(): a loop over up to 16 slices of pk_step() incl. winner election and LDS exchange;
+                           the straight-line body is ordered by schedule().
+  QOA_BLOCK_SPEC_ASM_TEXT  pk_block(spec=True): the same loop on speculative steps (30 / 33 instructions).
 """
 import os
 
