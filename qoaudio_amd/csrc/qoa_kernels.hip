@@ -236,6 +236,8 @@ __device__ __forceinline__ void run_slice_asm(unsigned tile_addr, int sf, const 
 // real audio or on the benchmark signals: qoa_encode_plan_stats() counts it, tests/test_gpu_parity.py checks the
 // reference's fixture and bench.py reports the workload's count).  After a 32-bit slice the state is
 // re-admitted by pk_try_pack(), which checks the ranges and the energy directly.
+// On top of this form sits the speculative one (run_block_spec): the same packed steps without the penalty arithmetic,
+// proven slice by slice from a sampled energy maximum; this full form is what a speculation miss falls back to.
 // ------------------------------------------------------------------------------------------------
 struct PkLms {
     unsigned w01, w23; // (w0, w1), (w2, w3): lower index in the low half
