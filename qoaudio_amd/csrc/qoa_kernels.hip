@@ -27,6 +27,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "qoa_format.h"
 #include "qoa_kernels.h"
 #include "qoa_slice_asm.inc"
@@ -736,6 +738,15 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 // into an LDS image of the frame's interleaved PCM (R rows = R*20 sample-times per frame group), and the
 // wave then copies the image out as 16-byte pieces of contiguous global memory.  The group stride in LDS
 // is an odd number of dwords, so the 2-byte scatter is bank-conflict free across frames.
+// compile-time counted loop: the body gets std::integral_constant<int, I> (asm "n" operands need true constants)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2 packed row.  A frame starts from i16 weights (they come from the header, src/lib.rs:276-281) and the history
 // is always i16, so the decoder can use the same i16-pair arithmetic as K1's fast path: 2 v_dot2_i32_i16 for the
@@ -1000,8 +1011,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     for (int r = 0; r < R; r++) cur[r] = load_row((unsigned)r);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // first group only: nothing is behind these loads yet
     for (unsigned row0 = 0; __builtin_amdgcn_ballot_w64(row0 < rows) != 0ull; row0 += R) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
+        static_for<0, R>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
             // in flight, oldest first: loads r..R-1 of this group, then the previous flush's NP stores
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cur[r]) : "n"(NP + R - 1 - r) : "memory");
             const unsigned hi = bswap32((unsigned)cur[r]), lo = bswap32((unsigned)(cur[r] >> 32));
@@ -1036,7 +1047,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
                 packed = fits_i16(l.w0) && fits_i16(l.w1) && fits_i16(l.w2) && fits_i16(l.w3);
                 dec_pack(l, pk);
             }
-        }
+        });
 #pragma unroll
         for (int r = 0; r < R; r++) cur[r] = load_row(row0 + R + (unsigned)r); // next group: issued before the stores below
         // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step.
