@@ -22,3 +22,15 @@ def test_c_header_is_plain_c(tmp_path):
                            str(tmp_path / "t"), "-L", os.path.join(ROOT, "qoaudio_amd"), "-lqoaudio_amd",
                            "-Wl,-rpath," + os.path.join(ROOT, "qoaudio_amd")])
     assert subprocess.run([str(tmp_path / "t")]).returncode == 0
+
+
+def _build_c_example(tmp_path):
+    exe = tmp_path / "roundtrip"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "roundtrip.c"), "-o", str(exe), "-L", os.path.join(ROOT, "qoaudio_amd"),
+                           "-lqoaudio_amd", "-Wl,-rpath," + os.path.join(ROOT, "qoaudio_amd"), "-lm"])
+    return exe
+
+
+def test_c_example_builds(tmp_path):
+    _build_c_example(tmp_path)

@@ -139,3 +139,12 @@ def test_wav_cli_round_trip(gpu, oracle, tmp_path):
     assert np.array_equal(got, want)
     assert cli.main(["info", mid]) == 0
     assert cli.main(["decode", src, dst]) == 1  # a WAV is not a QOA file
+
+
+def test_c_example_round_trip(gpu, tmp_path):
+    """examples/roundtrip.c: the C ABI from plain C, encode_all + decode_all on host buffers."""
+    import subprocess
+    from test_cpp_mirror_builds import _build_c_example
+    r = subprocess.run([str(_build_c_example(tmp_path))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "176400 samples" in r.stdout and "2 ch, 44100 Hz" in r.stdout
