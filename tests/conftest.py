@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libqoaudio_amd.so (it is git-ignored): build it once for the suite.  hipcc
+    cross-compiles for gfx950 without a GPU.  (The product itself never builds or falls back: qoaudio_amd._lib
+    raises if the library is missing.)"""
+    import subprocess
+    so = os.path.join(ROOT, "qoaudio_amd", "libqoaudio_amd.so")
+    srcs = [os.path.join(ROOT, "qoaudio_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "qoaudio_amd", "csrc"))
+            if f.endswith((".hip", ".cpp", ".h", ".inc"))] + [os.path.join(ROOT, "include", "qoaudio_amd.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "qoaudio_amd", "csrc")], stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def fixture_bytes():
     with open(FIXTURE, "rb") as f:
