@@ -462,8 +462,12 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // sample tiles [wave][chain][kTileInts] + one slice of slack: the block loop prefetches one slice past its last
     __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts + 20];
     // candidate end states of the slice in flight; two buffers: the speculative loop alternates between them so that
-    // a slice's entry state (the previous winner's slot) survives until the slice is known to be final
-    __shared__ __attribute__((aligned(256))) uint4 s_cand[2][4][CPW][16];
+    // a slice's entry state (the previous winner's slot) survives until the slice is known to be final.  It switches
+    // buffers with one v_xor of the slot address, so the pair must be aligned to its own size (and a row's 16 slots to
+    // 256 bytes for the winner-address trick).
+    constexpr unsigned kCandBufBytes = 4u * CPW * 16u * sizeof(uint4);
+    static_assert((kCandBufBytes & (kCandBufBytes - 1)) == 0, "buffer size must be a power of two");
+    __shared__ __attribute__((aligned(2 * kCandBufBytes))) uint4 s_cand[2][4][CPW][16];
     // [0,16): the block's winning slices, [16,32): per-lane dummies; 48 entries = 384 B per chain so that the two
     // chains a 64-lane ds_write_b64 serves per pass fall on disjoint banks
     __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][48];
@@ -480,7 +484,6 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     uint2 *out_tile = s_out[wave_in_block][grp];
     typedef __attribute__((address_space(3))) void *lds_ptr;
     const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[0][wave_in_block][grp][sf];
-    constexpr unsigned kCandBufBytes = 4u * CPW * 16u * sizeof(uint4);
     const unsigned outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
 
     const EncChain ch = chains[chain_id];
