@@ -33,6 +33,10 @@
 #include "qoa_kernels.h"
 #include "qoa_slice_asm.inc"
 
+#ifndef QOA_DEC_DEPTH
+#define QOA_DEC_DEPTH 2
+#endif
+
 namespace qoa {
 
 __constant__ int c_recip[16] = QOA_RECIPROCALS;
@@ -1013,22 +1017,23 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     // have in flight; requested a whole group earlier it has that group's decode time to come back.  Two register
     // sets, used alternately (a set is refilled by the group that just consumed it -- never copied: the registers of a
     // load in flight must not be read).
-    unsigned long long buf[2][R];
+    constexpr int D = QOA_DEC_DEPTH; // groups of slices in flight
+    unsigned long long buf[D][R];
 #pragma unroll
-    for (int r = 0; r < R; r++) buf[0][r] = load_row((unsigned)r);
+    for (int d = 0; d < D; d++)
 #pragma unroll
-    for (int r = 0; r < R; r++) buf[1][r] = load_row((unsigned)(R + r));
+        for (int r = 0; r < R; r++) buf[d][r] = load_row((unsigned)(d * R + r));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the first two groups: nothing is behind these loads yet
-    for (unsigned row00 = 0; __builtin_amdgcn_ballot_w64(row00 < rows) != 0ull; row00 += 2 * R) {
-      static_for<0, 2>([&](auto pc) {
+    for (unsigned row00 = 0; __builtin_amdgcn_ballot_w64(row00 < rows) != 0ull; row00 += D * R) {
+      static_for<0, D>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         const unsigned row0 = row00 + (unsigned)(p * R);
-        if (p == 1 && __builtin_amdgcn_ballot_w64(row0 < rows) == 0ull) return; // the wave's frames ended in the first half
+        if (p > 0 && __builtin_amdgcn_ballot_w64(row0 < rows) == 0ull) return; // the wave's frames ended earlier in this round
         static_for<0, R>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             // in flight, oldest first: loads r..R-1 of this group, the NP stores of the flush before last, the next
             // group's R loads, the last flush's NP stores
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[p][r]) : "n"(2 * NP + 2 * R - 1 - r) : "memory");
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[p][r]) : "n"(D * NP + D * R - 1 - r) : "memory");
             const unsigned hi = bswap32((unsigned)buf[p][r]), lo = bswap32((unsigned)(buf[p][r] >> 32));
             const unsigned *deq_row = s_deq[hi >> 28];
             const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
@@ -1063,7 +1068,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
             }
         });
 #pragma unroll
-        for (int r = 0; r < R; r++) buf[p][r] = load_row(row0 + 2 * R + (unsigned)r); // the group after next, before the stores below
+        for (int r = 0; r < R; r++) buf[p][r] = load_row(row0 + D * R + (unsigned)r); // D groups ahead, before the stores below
         // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step.
         // All LDS reads first (one wait), then NP unconditional stores.
         typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(2)));
