@@ -319,7 +319,7 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
                    [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
                    [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
                    [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0xf0)
-                 : "vcc", "scc", "memory", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
+                 : "vcc", "scc", "memory", "s95", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
                    "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
                    "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
                    "v121", "v122", "v123", "v124", "v125", "v126", "v127");
@@ -348,7 +348,7 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
                    [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
                    [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),
                    [mf0] "s"(0xf0), [pp] "s"(pp)
-                 : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                 : "vcc", "scc", "memory", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
                    "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
                    "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
                    "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",

@@ -100,7 +100,8 @@ PK_OPERANDS = dict(w01="%[w01]", w23="%[w23]", pen="%[pen]", e="%[e]", acca="%[a
 # The block loop keeps everything that lives across slices in fixed registers (the statement's in/out operands are
 # register variables bound to v[84:87]): v[80:81] slice words, v[82:83] rank, v[84:87] packed state.
 PK_FIXED = dict(w01="v84", w23="v85", pen="v88", e="v[82:83]", acca="v89", accb="v90", aerr0="v79",
-                R=["v87", "v124", "v86", "v125"], alt=[f"v{r}" for r in range(67, 76)], qm="v66")
+                R=["v87", "v124", "v86", "v125"], alt=[f"v{r}" for r in range(67, 76)], qm="v66",
+                one2="s95")  # 0x00010001 in an SGPR: a 4-byte v_or instead of 8 (a lone wave runs close to its fetch rate)
 
 
 def pk_step(i, N=PK_OPERANDS, spec=False):
@@ -130,7 +131,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}" if pen_full or check else None,
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",   # the inline 15 has no high half to select
         slot_a,
-        f"v_or_b32 {SB}, 0x10001, {SB}",                    # (+-1, +-1) for B_n
+        f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",  # (+-1, +-1) for B_n
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
         f"v_ashrrev_i32 {X}, 18, {Q}" if pen_full else None,
         f"v_sub_u32 {T}, {smp}, {PR}",                      # residual
@@ -179,8 +180,8 @@ def pk_prologue(N, zero=True):
         f"v_alignbit_b32 {R[3]}, {R[0]}, {R[2]}, 16",        # B_(-1) = (h1, h2)
         f"v_pk_ashrrev_i16 {S[2]}, 15, {R[2]} op_sel_hi:[0,1]",
         f"v_pk_ashrrev_i16 {S[3]}, 15, {R[3]} op_sel_hi:[0,1]",
-        f"v_or_b32 {S[2]}, 0x10001, {S[2]}",
-        f"v_or_b32 {S[3]}, 0x10001, {S[3]}",
+        f"v_or_b32 {S[2]}, {N.get('one2', '0x10001')}, {S[2]}",
+        f"v_or_b32 {S[3]}, {N.get('one2', '0x10001')}, {S[3]}",
     ] + (pk_zero(N) if zero else [])
 
 
@@ -327,6 +328,7 @@ def pk_block(verbose=False, spec=False):
     zero = [f"v_mov_b64 {N['e']}, 0"] + ([] if spec else [f"v_mov_b32 {N['pen']}, 0"])
     L = []
     L += [
+        "s_mov_b32 s95, 0x10001",
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an early exit restores
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
