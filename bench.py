@@ -6,11 +6,19 @@ A step = one pass of the hot path over one batch: every rank encodes 1024 synthe
 clips of 256 frames (BASELINE config 3's shape; 2,684,354,560 int16 samples, 5.37 GB of PCM resident in
 HBM before the timed region) and, for N > 1, the encoded buffers (1.08 GB per rank) are gathered to
 rank 0 with RCCL (config 4).  value = samples all ranks encoded / time of the K steps (max over ranks).
+
+N > 1 runs one process per GPU.  Under `python -m torch.distributed.run` the ranks already exist (RANK /
+WORLD_SIZE in the environment); started plainly as `python bench.py --gpus N` this process becomes a launcher
+that never touches the GPU: it starts N rank processes of this same script and exits with their status.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,18 +31,33 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+KERNEL_SOURCES = {"encode": ("qoa_kernels.hip", "qoa_slice_asm.inc", "qoa_device.h"),
+                  "decode": ("qoa_decode.hip", "qoa_device.h")}
+
+
+def kernel_source_sha256(kernel: str) -> str:
+    """sha256 over the source files a kernel is built from: ties a committed PMC profile to the build it was taken on."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[kernel]:
+        with open(os.path.join(ROOT, "qoaudio_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC profile (profiles/pmc_traffic.json: separate --pmc
-    passes, FETCH_SIZE doubled per the gfx950 correction).  PMC counters cannot be read from inside this process,
-    so the number is only reported for the exact workload it was collected on; otherwise null."""
+    """(HBM bytes per launch, note) from the committed rocprofv3 PMC profile (profiles/pmc_traffic.json: separate
+    --pmc passes, FETCH_SIZE doubled per the gfx950 correction; tools/pmc.sh + tools/pmc_traffic.py write it).  PMC
+    counters cannot be read from inside this process, so the number is only reported for the exact workload AND the
+    exact kernel sources it was collected on; otherwise null with the reason."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/pmc_traffic.json"
     if (clips, channels, frames) != (1024, 2, 256):
-        return None
-    return d[kernel]["traffic_bytes_per_launch"]
-
+        return None, "PMC profile was collected on config 3 (1024 x 2 ch x 256 frames) only"
+    if d[kernel].get("source_sha256") != kernel_source_sha256(kernel):
+        return None, "traffic_stale: kernel sources changed since the PMC profile " + str(d.get("source"))
+    return d[kernel]["traffic_bytes_per_launch"], None
 
 def valu_issue(n_chains: int, samples: int, kernel_ms: float):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
@@ -48,39 +71,63 @@ def valu_issue(n_chains: int, samples: int, kernel_ms: float):
             "frac": achieved / peak, "wavefronts": waves}
 
 
-def cpu_baseline(pcm_host: np.ndarray, channels: int, rate: int, budget_s: float):
-    """The CPU oracle's ref_style encoder (the reference's algorithm incl. its rank-sorted early exits),
-    one thread, on a bounded sample of the same clips.  kind = "port": the Rust reference cannot be built here."""
-    from oracle import oracle as O
-    O.lib()
-    n = 0
-    samples = pcm_host.shape[1]
-    t0 = time.perf_counter()
-    outs = []
-    for i in range(pcm_host.shape[0]):
-        outs.append(O.encode_all(pcm_host[i].reshape(-1), channels, rate, samples, O.REF_STYLE))
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return n * samples * channels / dt, n, dt, outs
+def cpu_baseline_child(pcm_host: np.ndarray, rate: int, budget_s: float):
+    """The CPU oracle's ref_style encoder (the reference's algorithm incl. its rank-sorted early exits) on a bounded
+    sample of the same clips: one thread, then all host cores.  Runs in a child process (oracle/cpu_bench.py) that
+    never touches the GPU, so its worker pool forks from a clean process.  kind = "port": the Rust reference cannot
+    be built here."""
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    fd, path = tempfile.mkstemp(prefix="qoa_bench_", suffix=".npy", dir=shm)
+    os.close(fd)
+    try:
+        np.save(path, pcm_host)
+        out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", path, str(rate), str(budget_s)], cwd=ROOT,
+                             check=True, capture_output=True, text=True).stdout
+    finally:
+        os.unlink(path)
+    return json.loads(out.strip().splitlines()[-1])
 
 
-def _cpu_worker(args):
-    pcm, channels, rate = args
-    from oracle import oracle as O
-    return len(O.encode_all(pcm.reshape(-1), channels, rate, pcm.shape[0], O.REF_STYLE))
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def cpu_all_cores(pcm_host: np.ndarray, channels: int, rate: int):
-    import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    clips = [pcm_host[i % pcm_host.shape[0]] for i in range(max(cores, min(4 * cores, 64)))]
-    with mp.get_context("fork").Pool(cores) as pool:
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker, [(c, channels, rate) for c in clips])
-        dt = time.perf_counter() - t0
-    return len(clips) * pcm_host.shape[1] * channels / dt, cores, len(clips), dt
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (fresh interpreters, one
+    per GPU) and wait.  This process makes no GPU call before or after (torch.cuda.device_count() does not initialise
+    the device).  Rank 0's JSON line goes straight to our stdout; any failing rank ends the others and fails the run."""
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
+                    for q in pending:  # exact PIDs we started
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -96,6 +143,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import qoaudio_amd as q
     from qoaudio_amd import batch, synth
@@ -166,6 +216,7 @@ def main():
     k_avg_ms = float(np.mean(kernel_ms))
     algo_bytes = plan.pcm_bytes + plan.out_bytes  # per launch: PCM read + QOA written (2.4039 B/sample)
     achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
+    enc_traffic, enc_traffic_note = pmc_traffic("encode", n_clips, ch, args.frames)
 
     result = {
         "metric": "encoded samples/sec (stereo 44.1 kHz)", "value": value, "unit": "samples/s",
@@ -179,13 +230,18 @@ def main():
                    "encoded_bytes_per_gpu": plan.out_bytes, "parallelism": f"clips sharded over {world} GPU(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("encode", n_clips, ch, args.frames), "kernel": "qoa_encode_kernel",
+                     "traffic": enc_traffic, "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md",
                      # the bound that actually governs K1 (profiles/r01i_pmc_summary.txt): 660 VALU wave-instructions
                      # per slice per wavefront, one per 4 cycles per SIMD at 2.4 GHz on 1024 SIMDs
                      "valu_issue": valu_issue(n_clips * ch, samples, k_avg_ms)},
     }
+    if enc_traffic_note:
+        result["roofline"]["traffic_note"] = enc_traffic_note
+    if world > 1:
+        result["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+        result["dist_backend"] = dist.get_backend()
 
     if rank == 0:
         # bit-exactness of this very run against the oracle, on a few clips (checker only, untimed)
@@ -198,7 +254,15 @@ def main():
         result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked, "speculation_misses": misses,
                                  "slices_total": (args.warmup + args.steps) * n_clips * ch * ((samples + 19) // 20)}
         if world > 1 and gathered is not None:
+            # the gather itself: the first clip of the first and of the last rank's shard, as they arrived on rank 0,
+            # against the oracle on that clip's PCM (regenerated here: clip indices are global)
             result["gathered_bytes"] = int(gathered.numel())
+            g_ok = True
+            for r in (0, world - 1):
+                one = synth.make_clips(1, samples, ch, args.rate, device=dev, first_index=r * n_clips)
+                want = O.encode_all(one[0].cpu().numpy().reshape(-1), ch, args.rate, samples)
+                g_ok = g_ok and gathered[r * n_clips].cpu().numpy().tobytes() == want
+            result["gathered_shards_bit_exact_vs_oracle"] = bool(g_ok)
 
     if not args.no_decode:
         dplan = batch.DecodePlan.from_clips(clips)
@@ -215,30 +279,36 @@ def main():
             dev_ms.append(e0.elapsed_time(e1))
         d_ms = float(np.mean(dev_ms))
         d_bytes = dplan.in_bytes + dplan.pcm_bytes
+        dec_traffic, dec_traffic_note = pmc_traffic("decode", n_clips, ch, args.frames)
         result["decode"] = {"value": dplan.samples / (d_ms * 1e-3), "unit": "samples/s", "kernel_ms_avg": d_ms,
                             "roofline": {"bound": "hbm", "achieved": d_bytes / (d_ms * 1e-3) / 1e9,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": d_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         "traffic": pmc_traffic("decode", n_clips, ch, args.frames),
+                                         "traffic": dec_traffic,
                                          "kernel": "qoa_decode_frames_kernel",
                                          "algorithmic_bytes_per_launch": d_bytes},
                             "header_mismatches": dplan.mismatches(),
                             "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt())}
+        if dec_traffic_note:
+            result["decode"]["roofline"]["traffic_note"] = dec_traffic_note
 
     if rank == 0 and world == 1 and not args.no_cpu:
         sample_clips = min(n_clips, 96)
         host = pcm[:sample_clips].cpu().numpy()
-        v1, n1, dt1, outs = cpu_baseline(host, ch, args.rate, args.cpu_seconds)
+        cpu = cpu_baseline_child(host, args.rate, args.cpu_seconds)
+        one, n1 = cpu["one_thread"], cpu["one_thread"]["clips"]
         he = out[:n1].cpu().numpy()
-        same = all(he[i].tobytes() == outs[i] for i in range(n1))
-        result["cpu_baseline"] = {"value": v1, "unit": "samples/s", "cores": 1, "kind": "port",
-                                  "sample": f"{n1} of the same {n_clips} clips ({n1 * samples * ch} samples, "
-                                            f"{dt1:.1f} s), oracle ref_style encoder, gcc -O3 -flto, 1 thread",
+        same = all(hashlib.sha256(he[i].tobytes()).hexdigest() == cpu["sha256"][i] for i in range(n1))
+        result["cpu_baseline"] = {"value": one["value"], "unit": "samples/s", "cores": 1, "kind": "port",
+                                  "sample": f"{n1} of the same {n_clips} clips ({one['samples']} samples, "
+                                            f"{one['seconds']:.1f} s), oracle ref_style encoder, gcc -O3 -flto, 1 thread",
                                   "gpu_bytes_equal_cpu_bytes": bool(same)}
-        va, cores, nc, dta = cpu_all_cores(host, ch, args.rate)
-        result["cpu_baseline"]["all_cores"] = {"value": va, "cores": cores,
-                                               "sample": f"{nc} clips, one clip per process, {dta:.1f} s"}
-        result["speedup_vs_cpu_1_thread"] = value / v1
+        if "all_cores" in cpu:
+            ac = cpu["all_cores"]
+            result["cpu_baseline"]["all_cores"] = {"value": ac["value"], "cores": ac["cores"],
+                                                   "sample": f"{ac['clips']} clips, one clip per process, "
+                                                             f"{ac['seconds']:.1f} s"}
+        result["speedup_vs_cpu_1_thread"] = value / one["value"]
 
     if rank == 0:
         print(json.dumps(result))

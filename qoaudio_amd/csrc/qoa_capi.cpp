@@ -635,6 +635,10 @@ struct DecTables {
     DevBuf frames[kMaxChannels + 1];
     unsigned n_frames[kMaxChannels + 1] = {0};
     bool whole_pieces[kMaxChannels + 1] = {false};
+    // K2u (qoa_decode.hip): uniform full frames of 1 / 2 channels whose PCM sits at a multiple of 16 bytes, in whole
+    // wavefronts of 64 / channels frames; what does not fill a wavefront stays in frames[]
+    DevBuf uframes[3];
+    unsigned n_uframes[3] = {0};
     DevBuf chains;
     unsigned n_chains = 0;
     DevBuf mismatch;
@@ -651,8 +655,27 @@ struct DecTables {
                 generic.push_back(e);
             }
         }
+        std::vector<DecChain> uni[3];
+        for (int n = 1; n <= 2; n++) {
+            std::vector<DecChain> rest;
+            for (const DecChain &d : per[n]) {
+                const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 16 == 0;
+                (uniform ? uni[n] : rest).push_back(d);
+            }
+            const size_t group = decode_uniform_group(n), keep = uni[n].size() / group * group;
+            rest.insert(rest.end(), uni[n].begin() + keep, uni[n].end());
+            uni[n].resize(keep);
+            per[n].swap(rest);
+        }
         hipError_t e = mismatch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
         if (e == hipSuccess) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
+        for (int n = 1; n <= 2 && e == hipSuccess; n++) {
+            n_uframes[n] = (unsigned)uni[n].size();
+            if (uni[n].empty()) continue;
+            e = uframes[n].reserve(uni[n].size() * sizeof(DecChain));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(uframes[n].p, uni[n].data(), uni[n].size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
+        }
         for (int n = 1; n <= kMaxChannels && e == hipSuccess; n++) {
             n_frames[n] = (unsigned)per[n].size();
             whole_pieces[n] = true;
@@ -672,13 +695,24 @@ struct DecTables {
         return e;
     }
     bool empty() const {
-        if (n_chains) return false;
+        if (n_chains || n_uframes[1] || n_uframes[2]) return false;
         for (int n = 1; n <= kMaxChannels; n++) if (n_frames[n]) return false;
         return true;
     }
     hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream) {
         hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream); // the count is per run
         if (e0 != hipSuccess) return e0;
+        for (int n = 1; n <= 2; n++) {
+            if (!n_uframes[n]) continue;
+            // K2u stores 16-byte pieces at frame offsets that are multiples of 16: with an odd base pointer (a caller's
+            // sub-buffer) the same table goes through the general kernel instead
+            hipError_t e = ((uintptr_t)d_out % 16 == 0)
+                               ? launch_decode_uniform(n, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n],
+                                                       (unsigned *)mismatch.p, stream)
+                               : launch_decode_frames(n, true, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n],
+                                                      (unsigned *)mismatch.p, (uint8_t *)mismatch.p + 64, stream);
+            if (e != hipSuccess) return e;
+        }
         for (int n = 1; n <= kMaxChannels; n++) {
             hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
                                                 (unsigned *)mismatch.p, (uint8_t *)mismatch.p + 64, stream);
@@ -859,6 +893,8 @@ extern "C" int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, i
 
 extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count) {
     if (!plan || !count) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    // the runs may sit on non-blocking side streams, which the null stream's copy below does not wait for
+    HIP_TRY(hipDeviceSynchronize(), QOA_DECODE_IO_ERROR);
     HIP_TRY(hipMemcpy(count, plan->t.mismatch.p, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
     return QOA_OK;
 }

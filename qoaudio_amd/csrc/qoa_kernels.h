@@ -29,6 +29,12 @@ hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *d_in,
                                 const DecChain *d_frames, unsigned n_frames, unsigned *d_mismatches,
                                 uint8_t *d_scratch, hipStream_t stream);
 
+// K2u, the fast path for uniform frames (rows == 256, n_out == 5120) of 1 or 2 channels: n_frames must be a multiple of
+// 64 / nch (whole wavefronts), every frame's PCM address 16-byte aligned.  kDecodeUniformFrames(nch) = that multiple.
+constexpr unsigned decode_uniform_group(int nch) { return nch == 1 ? 64u : nch == 2 ? 32u : 0u; }
+hipError_t launch_decode_uniform(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames, unsigned n_frames,
+                                 unsigned *d_mismatches, hipStream_t stream);
+
 // test hook: one slice, 16 candidates (device pointers; tot/fst/slice: 16 x u64, end_state: 16 x 8 x i32)
 hipError_t launch_debug_slice(const int32_t *d_state, const int32_t *d_samples, int len, int generic,
                               unsigned long long *d_tot, unsigned long long *d_fst, unsigned long long *d_slice,

@@ -33,45 +33,9 @@
 #include "qoa_kernels.h"
 #include "qoa_slice_asm.inc"
 
-#ifndef QOA_DEC_DEPTH
-#define QOA_DEC_DEPTH 2
-#endif
+#include "qoa_device.h"
 
 namespace qoa {
-
-__constant__ int c_recip[16] = QOA_RECIPROCALS;
-__constant__ int c_mags[16][4] = QOA_DEQUANT_MAGS;
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-// 24-bit multiply-add as a single instruction with EXACT wrapping semantics: the low 32 bits of
-// sext24(a) * sext24(b) + c.  Not HIP's __mul24: that is `mul nsw` in the device library, i.e. signed
-// overflow is undefined, and hipcc then narrows a u64 rank sum to 32 bits (caught by the parity tests:
-// err^2 reaches 2^32).  Inline asm keeps the instruction and drops the assumption.
-__device__ __forceinline__ int mad24(int a, int b, int c) {
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ int mul32(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
-// clamp(v, lo, hi); the backend folds min(max()) with constant bounds into one v_med3_i32
-__device__ __forceinline__ int med3(int v, int lo, int hi) { return min(max(v, lo), hi); }
-__device__ __forceinline__ unsigned uabs(int v) { unsigned s = (unsigned)(v >> 31); return ((unsigned)v ^ s) - s; }
-
-struct Lms {
-    int h0, h1, h2, h3; // history, oldest first (src/lib.rs:72)
-    int w0, w1, w2, w3; // weights (src/lib.rs:73)
-};
-
-// full 32-bit wrapping multiply-add in ONE instruction: the low dword of v_mad_u64_u32.  Measured on gfx950
-// (tools/ubench): same issue cost as v_mad_i32_i24 and as v_mul_lo_u32, so the dot products need no 24-bit
-// operand guard and no second code path.  The high dword is garbage and ignored.
-__device__ __forceinline__ unsigned long long mad32(int a, int b, unsigned long long acc) {
-    unsigned long long r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
-    return r;
-}
 
 struct CandResult {
     Lms lms;                 // end state of this candidate
@@ -168,10 +132,6 @@ __device__ __forceinline__ void cand_step(int smp, const StepConst &k, Lms &l, i
     l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
     s0 = s1; s1 = s2; s2 = s3; s3 = ns3;
     err_out = err;
-}
-
-__device__ __forceinline__ void sign_mults(const Lms &l, int &s0, int &s1, int &s2, int &s3) {
-    s0 = (l.h0 >> 31) | 1; s1 = (l.h1 >> 31) | 1; s2 = (l.h2 >> 31) | 1; s3 = (l.h3 >> 31) | 1;
 }
 
 // A full 20-sample slice, fully unrolled (the history shift is register renaming).
@@ -426,7 +386,6 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
     return row_min_u32(k2) & 15u;
 }
 
-__device__ __forceinline__ unsigned bswap32(unsigned v) { return __builtin_bswap32(v); }
 
 // ------------------------------------------------------------------------------------------------
 // K1: encode
@@ -728,391 +687,6 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
     o[0] = r.lms.h0; o[1] = r.lms.h1; o[2] = r.lms.h2; o[3] = r.lms.h3;
     o[4] = r.lms.w0; o[5] = r.lms.w1; o[6] = r.lms.w2; o[7] = r.lms.w3;
 }
-
-// ------------------------------------------------------------------------------------------------
-// K2: decode
-//
-// A decode chain is one (stream, frame, channel): the LMS state is re-seeded from every frame header
-// (src/lib.rs:270-281), so frames are independent.  One lane per chain, 20 steps per slice
-// (src/lib.rs:306-317): predict on full 32-bit multiplies (a hostile stream can drive decoder weights
-// anywhere), dequantise with the slice's four magnitudes (read once per slice from a 16-entry LDS table)
-// through v_perm_b32, clamp, LMS update.
-//
-// I/O.  Input: each lane reads its own 8-byte slice per row (channels of a frame are adjacent lanes, so a
-// wave touches 64/NCH lines per row and re-uses each line for 128/(8 NCH) rows out of L1/L2); the next
-// row's slice is loaded before the current one is decoded.  Output: int16 samples at stride NCH are
-// scattered 2 bytes at a time, which a global store cannot coalesce -- so every lane writes its samples
-// into an LDS image of the frame's interleaved PCM (R rows = R*20 sample-times per frame group), and the
-// wave then copies the image out as 16-byte pieces of contiguous global memory.  The group stride in LDS
-// is an odd number of dwords, so the 2-byte scatter is bank-conflict free across frames.
-// compile-time counted loop: the body gets std::integral_constant<int, I> (asm "n" operands need true constants)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2 packed row.  A frame starts from i16 weights (they come from the header, src/lib.rs:276-281) and the history
-// is always i16, so the decoder can use the same i16-pair arithmetic as K1's fast path: 2 v_dot2_i32_i16 for the
-// prediction, 2 v_pk_mad_i16 for the update.  Exactness is a per-row guard here: one sample moves a weight by at
-// most |dequant >> 4| <= ceil(mag3(sf) / 16), so a row of 20 samples whose weights all satisfy
-// |w| + 20 * ceil(mag3 / 16) <= 32767 at its start cannot leave i16; the products are then exact and the i32
-// accumulation of v_dot2 is the reference's wrapping sum (src/lib.rs:799-805).  Rows that fail the guard (a hostile
-// stream can drive decoder weights anywhere) run the 32-bit step from the unpacked state, for the whole wave.
-// ------------------------------------------------------------------------------------------------
-typedef short pk_i16 __attribute__((ext_vector_type(2)));
-
-struct DecPk {
-    unsigned w01, w23;   // (w0, w1), (w2, w3)
-    unsigned pa, pm, pb; // history (h0, h1), (h1, h2), (h2, h3)
-    unsigned sa, sm, sb; // their +-1 pairs
-};
-
-__device__ __forceinline__ unsigned pk_signs(unsigned pair) {
-    const pk_i16 v = __builtin_bit_cast(pk_i16, pair);
-    const pk_i16 m = v >> (pk_i16){15, 15};
-    return __builtin_bit_cast(unsigned, m) | 0x00010001u;
-}
-
-__device__ __forceinline__ void dec_pack(const Lms &l, DecPk &p) {
-    auto pack = [](int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); };
-    p.w01 = pack(l.w0, l.w1); p.w23 = pack(l.w2, l.w3);
-    p.pa = pack(l.h0, l.h1); p.pm = pack(l.h1, l.h2); p.pb = pack(l.h2, l.h3);
-    p.sa = pk_signs(p.pa); p.sm = pk_signs(p.pm); p.sb = pk_signs(p.pb);
-}
-
-__device__ __forceinline__ void dec_unpack(const DecPk &p, Lms &l, int &s0, int &s1, int &s2, int &s3) {
-    l.w0 = (int)(p.w01 << 16) >> 16; l.w1 = (int)p.w01 >> 16;
-    l.w2 = (int)(p.w23 << 16) >> 16; l.w3 = (int)p.w23 >> 16;
-    l.h0 = (int)(p.pa << 16) >> 16; l.h1 = (int)p.pa >> 16;
-    l.h2 = (int)(p.pb << 16) >> 16; l.h3 = (int)p.pb >> 16;
-    sign_mults(l, s0, s1, s2, s3);
-}
-
-// |w_i| <= limit for the four packed weights (limit in 0..32767)
-__device__ __forceinline__ bool dec_weights_within(const DecPk &p, int limit) {
-    const pk_i16 a = __builtin_bit_cast(pk_i16, p.w01), b = __builtin_bit_cast(pk_i16, p.w23);
-    const pk_i16 hi = __builtin_elementwise_max(a, b), lo = __builtin_elementwise_min(a, b);
-    return hi.x <= limit && hi.y <= limit && lo.x >= -limit && lo.y >= -limit;
-}
-
-__device__ __forceinline__ bool fits_i16(int v) { return (unsigned)(v + 32768) < 65536u; }
-
-// One decoded sample on the packed state.  `entry` comes from the LDS dequant table: low half = the dequantised
-// residual (src/lib.rs:309), high half = that value >> 4, the weight step of src/lib.rs:822 -- so the sample costs no
-// code-to-magnitude arithmetic at all, and the 20 lookups of a row are issued ahead of its serial chain.
-// B_i = (h[i-2], h[i-1]); the three live history pairs rotate by name in the unrolled caller.
-__device__ __forceinline__ int decode_step_pk(unsigned &w01, unsigned &w23, unsigned A, unsigned B, unsigned SA, unsigned SB,
-                                              unsigned &Bn, unsigned entry) {
-    int p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w01), __builtin_bit_cast(pk_i16, A), 0, false);
-    p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w23), __builtin_bit_cast(pk_i16, B), p, false);
-    const int deq = (int)(short)(entry & 0xffffu);
-    const int recon = med3((p >> 13) + deq, -32768, 32767);
-    const short delta = (short)(entry >> 16);
-    const pk_i16 d2 = {delta, delta};
-    w01 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SA) * d2 + __builtin_bit_cast(pk_i16, w01)));
-    w23 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SB) * d2 + __builtin_bit_cast(pk_i16, w23)));
-    Bn = __builtin_amdgcn_alignbit((unsigned)recon, B, 16); // (h3, recon)
-    return recon;
-}
-
-// LDS dequant table for the packed rows: [sf][code] = (dequant & 0xffff) | ((dequant >> 4) << 16)
-__device__ __forceinline__ void init_deq_table(unsigned (*s_deq)[8]) {
-    if (threadIdx.x < 128) {
-        const unsigned sf = threadIdx.x >> 3, code = threadIdx.x & 7u;
-        const int mag = c_mags[sf][code >> 1];
-        const int deq = (code & 1u) ? -mag : mag; // QOA_DEQUANT_TAB, src/lib.rs:847-864
-        s_deq[sf][code] = ((unsigned)deq & 0xffffu) | ((unsigned)(deq >> 4) << 16);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void decode_init_lms(const uint8_t *f, unsigned channel, Lms &l) {
-    // 4 x i16 history, 4 x i16 weights, big-endian, sign-extended (src/lib.rs:271-281)
-    const unsigned *s = (const unsigned *)(f + 8 + 16 * (size_t)channel);
-    unsigned a = bswap32(s[0]), b = bswap32(s[1]), c = bswap32(s[2]), d = bswap32(s[3]);
-    l.h0 = (int)a >> 16; l.h1 = (int)(a << 16) >> 16; l.h2 = (int)b >> 16; l.h3 = (int)(b << 16) >> 16;
-    l.w0 = (int)c >> 16; l.w1 = (int)(c << 16) >> 16; l.w2 = (int)d >> 16; l.w3 = (int)(d << 16) >> 16;
-}
-
-// One decoded sample (src/lib.rs:307-316).  `code` is the 3-bit quantised residual.
-__device__ __forceinline__ int decode_step(Lms &l, int &s0, int &s1, int &s2, int &s3, unsigned code, unsigned dq_lo,
-                                           unsigned dq_hi) {
-    unsigned long long acc = (unsigned long long)(unsigned)mul32(l.w0, l.h0);
-    acc = mad32(l.w1, l.h1, acc);
-    acc = mad32(l.w2, l.h2, acc);
-    acc = mad32(l.w3, l.h3, acc);
-    int pred = (int)(unsigned)acc >> 13;
-    int sneg = -(int)(code & 1u);
-    unsigned sel = (code & 6u) * 0x0101u + 0x0c0c0100u;
-    int mag = (int)__builtin_amdgcn_perm(dq_hi, dq_lo, sel);
-    int deq = (mag ^ sneg) - sneg;
-    int recon = med3(pred + deq, -32768, 32767);
-    int delta = deq >> 4;
-    l.w0 = mad24(s0, delta, l.w0); l.w1 = mad24(s1, delta, l.w1);
-    l.w2 = mad24(s2, delta, l.w2); l.w3 = mad24(s3, delta, l.w3);
-    l.h0 = l.h1; l.h1 = l.h2; l.h2 = l.h3; l.h3 = recon;
-    s0 = s1; s1 = s2; s2 = s3; s3 = (recon >> 31) | 1;
-    return recon;
-}
-
-__device__ __forceinline__ void init_mag_table(uint2 *s_mags) {
-    if (threadIdx.x < 16) {
-        s_mags[threadIdx.x] = make_uint2((unsigned)c_mags[threadIdx.x][0] | ((unsigned)c_mags[threadIdx.x][1] << 16),
-                                         (unsigned)c_mags[threadIdx.x][2] | ((unsigned)c_mags[threadIdx.x][3] << 16));
-    }
-    __syncthreads();
-}
-
-// K2 generic: any channel count (1..255), one lane per chain, direct 2-byte global stores.  Used for the
-// exotic streams only (more than 8 channels); everything else goes through qoa_decode_frames_kernel.
-__global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
-                                                         const DecChain *__restrict__ chains, unsigned n_chains,
-                                                         unsigned *__restrict__ mismatches) {
-    __shared__ uint2 s_mags[16];
-    init_mag_table(s_mags);
-    const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_chains) return;
-    const DecChain ch = chains[id];
-    const uint8_t *f = in + ch.frame_off;
-    const unsigned nch = ch.channels;
-    if ((ch.expect_hi | ch.expect_lo) != 0 && ch.channel == 0) {
-        unsigned hi = bswap32(*(const unsigned *)f), lo = bswap32(*(const unsigned *)(f + 4));
-        if (hi != ch.expect_hi || lo != ch.expect_lo) atomicAdd(mismatches, 1u);
-    }
-    Lms l;
-    decode_init_lms(f, ch.channel, l);
-    int s0, s1, s2, s3;
-    sign_mults(l, s0, s1, s2, s3);
-    const uint8_t *sp = f + 8 + 16 * (size_t)nch + 8 * (size_t)ch.channel;
-    int16_t *op = out + ch.out_off;
-    unsigned remaining = ch.n_out;
-    for (unsigned row = 0; row < ch.rows; row++) {
-        const unsigned hi = bswap32(*(const unsigned *)sp), lo = bswap32(*(const unsigned *)(sp + 4));
-        sp += 8 * (size_t)nch;
-        const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
-        const uint2 dq = s_mags[hi >> 28];
-        int16_t rec[20];
-#pragma unroll
-        for (int i = 0; i < 20; i++)
-            rec[i] = (int16_t)decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
-        const unsigned n = min(remaining, 20u); // tail: only `remaining` samples are exposed (src/lib.rs:320-328)
-#pragma unroll
-        for (int i = 0; i < 20; i++) if ((unsigned)i < n) op[(size_t)i * nch] = rec[i];
-        op += (size_t)20 * nch;
-        remaining -= n;
-    }
-}
-
-// K2: NCH in 1..8, one table entry per FRAME, 64/NCH frames per wavefront, LDS-transposed output.
-// `scratch` points at kDecodeScratchBytes of device memory that absorbs the 16-byte stores of pieces that lie
-// beyond a frame's end: making every flush store unconditional keeps their count static, so hipcc can wait
-// for the prefetched slice with a counted vmcnt instead of draining the stores.
-template <int NCH, int R, int WPB, bool PARTIAL>
-__global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
-                                                                const DecChain *__restrict__ frames, unsigned n_frames,
-                                                                unsigned *__restrict__ mismatches,
-                                                                uint8_t *__restrict__ scratch) {
-    constexpr int FPW = 64 / NCH;               // frame groups per wavefront
-    constexpr int GS = R * 20 * NCH * 2;        // bytes of one group's PCM image (R rows)
-    constexpr int GSP = GS + 4;                 // odd dword stride: conflict-free 2-byte scatter across groups
-    constexpr int PPG = GS / 16;                // 16-byte pieces per group image
-    constexpr int NP = (FPW * PPG + 63) / 64;   // pieces per lane per flush
-    static_assert(GS % 16 == 0, "group image must be a whole number of 16-byte pieces");
-    // When NCH does not divide 64 the last few lanes of a wave belong to no frame group (g == FPW).  They run the same
-    // code -- they serve flush pieces, ballots and bpermutes -- so they need an image slot of their own to scribble
-    // into: without it their row writes land in the NEXT wave's image (found by fuzzing multi-wave 3/5/6/7-channel
-    // batches; tests/test_gpu_parity.py::test_decode_channel_counts_that_do_not_divide_64).
-    constexpr int IMG_GROUPS = FPW + ((64 % NCH) ? 1 : 0);
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][IMG_GROUPS * GSP + 12];
-    __shared__ uint2 s_mags[16];
-    __shared__ unsigned s_deq[16][8];
-    init_deq_table(s_deq);
-    init_mag_table(s_mags); // (ends with the block barrier)
-
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned g = lane / NCH, c = lane % NCH;
-    const unsigned frame_id = (blockIdx.x * (unsigned)WPB + wave) * FPW + g;
-    const bool valid = (g < (unsigned)FPW) && frame_id < n_frames;
-    DecChain fr;
-    if (valid) fr = frames[frame_id];
-    else { fr.frame_off = 0; fr.out_off = 0; fr.n_out = 0; fr.rows = 0; fr.channels = NCH; fr.channel = 0; fr.expect_hi = fr.expect_lo = 0; }
-    const unsigned rows = valid ? fr.rows : 0u;
-    const uint8_t *f = in + fr.frame_off;
-    Lms l = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (valid) {
-        if ((fr.expect_hi | fr.expect_lo) != 0 && c == 0) {
-            unsigned hi = bswap32(*(const unsigned *)f), lo = bswap32(*(const unsigned *)(f + 4));
-            if (hi != fr.expect_hi || lo != fr.expect_lo) atomicAdd(mismatches, 1u);
-        }
-        decode_init_lms(f, c, l);
-    }
-    int s0, s1, s2, s3;
-    sign_mults(l, s0, s1, s2, s3);
-    DecPk pk;          // the chain's state while `packed` (l is then stale)
-    bool packed = true; // header values are i16
-    dec_pack(l, pk);
-    // Slice loads are UNCONDITIONAL and clamped (a branch around a load makes hipcc wait for it at the join,
-    // i.e. immediately): lanes without a frame, and rows past a frame's end, re-read a valid slice of lane 0's
-    // frame -- every table entry has rows >= 1 -- and ignore it.
-    const uint8_t *sp = f + 8 + 16 * NCH + 8 * c;
-    unsigned rows_ld = rows;
-    {
-        const unsigned long long p0 = (unsigned long long)sp; // lane 0 of the wave holds the wave's first frame
-        const unsigned lo0 = __builtin_amdgcn_readfirstlane((unsigned)p0);
-        const unsigned hi0 = __builtin_amdgcn_readfirstlane((unsigned)(p0 >> 32));
-        const unsigned rows0 = __builtin_amdgcn_readfirstlane(rows);
-        if (rows0 == 0) return; // whole wave beyond the table
-        if (!valid) {
-            sp = (const uint8_t *)(((unsigned long long)hi0 << 32) | lo0);
-            rows_ld = rows0;
-        }
-    }
-    uint8_t *img = s_img[wave];
-    const unsigned my_img = g * GSP + c * 2;
-
-    // Flush plan, fixed for the whole kernel: piece t of this lane is 16 bytes at byte k*16 of group gg's image.
-    // ptr[t] walks the group's output by GS bytes per flush; left[t] = bytes of the frame's output that remain
-    // at and after this piece (<= 0: nothing to store).
-    unsigned long long ptr[NP];
-    int left[NP];
-    unsigned src_off[NP];
-    {
-        const unsigned long long my_out = (unsigned long long)(out + fr.out_off);
-        const int my_bytes = (int)(fr.n_out * (unsigned)(NCH * 2));
-#pragma unroll
-        for (int t = 0; t < NP; t++) {
-            const unsigned p = lane + 64u * t;
-            const unsigned gg = min(p / PPG, (unsigned)(FPW - 1)), k = p % PPG;
-            const int from = (int)((gg * NCH) << 2);
-            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)my_out);
-            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(my_out >> 32));
-            const int bytes = __builtin_amdgcn_ds_bpermute(from, my_bytes);
-            ptr[t] = ((((unsigned long long)hi) << 32) | lo) + k * 16;
-            left[t] = (p < (unsigned)(FPW * PPG)) ? bytes - (int)(k * 16) : 0;
-            src_off[t] = gg * GSP + k * 16;
-        }
-    }
-    uint8_t *const dummy = scratch + lane * 16;
-
-    // Slice loads.  vmcnt retires loads and stores in issue order, so a load issued AFTER a flush's stores cannot be
-    // waited for without waiting for those stores to reach memory first (a ~6 us stall per flush when the next
-    // row's slice was fetched one row ahead).  Hence the R slices of the NEXT group are requested together, right
-    // before the current group's flush stores, and row r of the next group waits with vmcnt(NP + R-1-r): its own
-    // load retired, the NP stores behind it still in flight.  hipcc cannot express that wait -- at the loop header
-    // it merges the pre-loop state (loads only) with the back edge (loads + stores) into a near-zero count -- so
-    // the loads and their waits are asm here, invisible to its vmcnt bookkeeping (the loop has no other loads).
-    auto load_row = [&](unsigned row) {
-        unsigned long long v;
-        const uint8_t *a = sp + (size_t)min(row, rows_ld - 1) * (8 * NCH);
-        // "memory": hipcc must not move its own loads/stores across this one -- the counted waits below rely on
-        // exactly NP (or more) stores being issued between these loads and the next group's first wait
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(a) : "memory");
-        return v;
-    };
-    // Two groups ahead: the CU's waves share one path into L1, so a load queues behind every store the other waves
-    // have in flight; requested a whole group earlier it has that group's decode time to come back.  Two register
-    // sets, used alternately (a set is refilled by the group that just consumed it -- never copied: the registers of a
-    // load in flight must not be read).
-    constexpr int D = QOA_DEC_DEPTH; // groups of slices in flight
-    unsigned long long buf[D][R];
-#pragma unroll
-    for (int d = 0; d < D; d++)
-#pragma unroll
-        for (int r = 0; r < R; r++) buf[d][r] = load_row((unsigned)(d * R + r));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the first two groups: nothing is behind these loads yet
-    for (unsigned row00 = 0; __builtin_amdgcn_ballot_w64(row00 < rows) != 0ull; row00 += D * R) {
-      static_for<0, D>([&](auto pc) {
-        constexpr int p = decltype(pc)::value;
-        const unsigned row0 = row00 + (unsigned)(p * R);
-        if (p > 0 && __builtin_amdgcn_ballot_w64(row0 < rows) == 0ull) return; // the wave's frames ended earlier in this round
-        static_for<0, R>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            // in flight, oldest first: loads r..R-1 of this group, the NP stores of the flush before last, the next
-            // group's R loads, the last flush's NP stores
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[p][r]) : "n"(D * NP + D * R - 1 - r) : "memory");
-            const unsigned hi = bswap32((unsigned)buf[p][r]), lo = bswap32((unsigned)(buf[p][r] >> 32));
-            const unsigned *deq_row = s_deq[hi >> 28];
-            const unsigned long long slice = ((unsigned long long)hi << 32) | lo;
-            unsigned entry[20];
-#pragma unroll
-            for (int i = 0; i < 20; i++) entry[i] = deq_row[(unsigned)(slice >> (57 - 3 * i)) & 7u];
-            // the largest weight step this row's scalefactor allows: |(-mag3) >> 4| = ceil(mag3 / 16), the code-7 entry
-            const int dmax = -((int)deq_row[7] >> 16);
-            const bool row_ok = packed && dec_weights_within(pk, 32767 - 20 * dmax);
-            if (__builtin_amdgcn_ballot_w64(!row_ok) == 0ull) {
-                // pair ring as in K1: B_i = (h[i-2], h[i-1]) lives in P[i % 4]; step i reads P[(i+2)%4] and P[i%4]
-                unsigned P[4] = {pk.pb, 0u, pk.pa, pk.pm}, S[4] = {pk.sb, 0u, pk.sa, pk.sm};
-#pragma unroll
-                for (int i = 0; i < 20; i++) {
-                    const int rec = decode_step_pk(pk.w01, pk.w23, P[(i + 2) % 4], P[i % 4], S[(i + 2) % 4], S[i % 4],
-                                                   P[(i + 1) % 4], entry[i]);
-                    S[(i + 1) % 4] = pk_signs(P[(i + 1) % 4]);
-                    *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
-                }
-                pk.pa = P[2]; pk.pm = P[3]; pk.pb = P[0]; // 20 % 4 == 0: the ring is back in place
-                pk.sa = S[2]; pk.sm = S[3]; pk.sb = S[0];
-            } else {
-                if (packed) dec_unpack(pk, l, s0, s1, s2, s3);
-                const uint2 dq = s_mags[hi >> 28];
-#pragma unroll
-                for (int i = 0; i < 20; i++) {
-                    int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
-                    *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
-                }
-                packed = fits_i16(l.w0) && fits_i16(l.w1) && fits_i16(l.w2) && fits_i16(l.w3);
-                dec_pack(l, pk);
-            }
-        });
-#pragma unroll
-        for (int r = 0; r < R; r++) buf[p][r] = load_row(row0 + D * R + (unsigned)r); // D groups ahead, before the stores below
-        // flush R rows of every frame group: LDS image -> contiguous global memory, 16 bytes per lane-step.
-        // All LDS reads first (one wait), then NP unconditional stores.
-        typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(2)));
-        typedef unsigned u32_alias __attribute__((may_alias));
-        asm volatile("" ::: "memory"); // the image was written as int16: keep the dword reads below behind those stores
-        u4_unaligned v[NP];
-#pragma unroll
-        for (int t = 0; t < NP; t++) {
-            const u32_alias *src = (const u32_alias *)(img + src_off[t]);
-            v[t] = u4_unaligned{src[0], src[1], src[2], src[3]};
-        }
-        asm volatile("" ::: "memory");
-        bool any_partial = false;
-#pragma unroll
-        for (int t = 0; t < NP; t++) {
-            // global address space spelled out: a generic pointer here becomes flat_store, which hipcc can only
-            // wait for with vmcnt(0) & lgkmcnt(0)
-            typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
-            const unsigned long long dst = left[t] >= 16 ? ptr[t] : (unsigned long long)dummy;
-// Non-temporal stores measured on MI355X (config-3 shapes): +13 % at 2 channels, +3 % at 4 and 8, but
-            // -8 % / -1.5 % at 1 / 3 channels (short odd-sized pieces) -> used for even channel counts only.
-            if (NCH % 2 == 0) __builtin_nontemporal_store(v[t], (gptr_t)dst);
-            else *(gptr_t)dst = v[t];
-            any_partial |= (left[t] > 0 && left[t] < 16);
-        }
-        // PARTIAL = false is launched when every frame's PCM is a whole number of 16-byte pieces (always true for
-        // full 5120-sample frames): with no store under a branch hipcc can count the stores and waits for the
-        // next prefetched slice with vmcnt(NP) instead of vmcnt(0), i.e. it never drains the write queue.
-        if (PARTIAL && __builtin_amdgcn_ballot_w64(any_partial) != 0ull) { // last piece of a short frame: 2-byte stores
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                if (left[t] > 0 && left[t] < 16) {
-                    const unsigned n16 = (unsigned)left[t] >> 1;
-                    const int16_t *src16 = (const int16_t *)(img + src_off[t]);
-                    for (unsigned q = 0; q < n16; q++) ((int16_t *)ptr[t])[q] = src16[q];
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NP; t++) { ptr[t] += GS; left[t] -= GS; }
-      });
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
@@ -1152,41 +726,6 @@ hipError_t launch_debug_slice(const int32_t *state, const int32_t *samples, int 
     hipLaunchKernelGGL(qoa_debug_slice_kernel, dim3(1), dim3(64), 0, stream, state, samples, len, generic, tot, fst,
                        slice, end_state);
     return hipGetLastError();
-}
-
-hipError_t launch_decode(const uint8_t *in, int16_t *out, const DecChain *chains, unsigned n, unsigned *mismatches,
-                         hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    dim3 g((n + 255) / 256), b(256);
-    hipLaunchKernelGGL(qoa_decode_kernel, g, b, 0, stream, in, out, chains, n, mismatches);
-    return hipGetLastError();
-}
-
-template <int R, int WPB, bool PARTIAL>
-static hipError_t launch_decode_frames_r(int nch, const uint8_t *in, int16_t *out, const DecChain *frames,
-                                         unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
-    dim3 b(64 * WPB);
-#define QOA_LAUNCH(N)                                                                                              \
-    case N: {                                                                                                      \
-        unsigned per_block = (unsigned)WPB * (64u / N);                                                            \
-        dim3 g((n_frames + per_block - 1) / per_block);                                                            \
-        hipLaunchKernelGGL((qoa_decode_frames_kernel<N, R, WPB, PARTIAL>), g, b, 0, stream, in, out, frames, n_frames, \
-                           mismatches, scratch);                                                                   \
-        break;                                                                                                     \
-    }
-    switch (nch) {
-        QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
-    default: return hipErrorInvalidValue;
-    }
-#undef QOA_LAUNCH
-    return hipGetLastError();
-}
-
-hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *in, int16_t *out, const DecChain *frames,
-                                unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
-    if (n_frames == 0) return hipSuccess;
-    if (whole_pieces) return launch_decode_frames_r<4, 4, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
-    return launch_decode_frames_r<4, 4, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
 }
 
 } // namespace qoa

@@ -1,0 +1,114 @@
+"""Static check of the decode kernels' code objects (CPU only: disassembles the gfx950 ELF inside libqoaudio_amd.so).
+
+K2 and K2u fetch their slices with asynchronous global loads whose results are consumed rows later.  If the
+destination were an ordinary asm output, hipcc would be free to copy or spill it between the load and its wait -- it
+believes the value is there when the asm statement ends -- and the kernel would decode garbage without any error.  The
+loads therefore target AccVGPRs, which hipcc does not allocate in these kernels, and only the statement that has
+waited for them moves them on.  This test pins that discipline down on the binary that ships:
+
+  * the only instructions that touch an AccVGPR are the slice loads (destination), `v_accvgpr_read_b32` and
+    `ds_write2_b64` (source);
+  * every one of those readers is preceded, in its basic block, by an `s_waitcnt vmcnt(..)` with no slice load in
+    between -- it cannot observe a load that is still in flight;
+  * no scratch (spill) instructions exist in the decode kernels.
+"""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+LIB = os.path.join(ROOT, "qoaudio_amd", "libqoaudio_amd.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(tmp_path):
+    """gfx950 ELF code objects of every translation unit bundled into the library's .hip_fatbin section."""
+    fat = tmp_path / "fat.bin"
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", LIB, str(tmp_path / "copy.so")])
+    blob = fat.read_bytes()
+    out = []
+    pos = blob.find(MAGIC)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", blob, pos + len(MAGIC))[0]
+        p = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tlen].decode()
+            p += 24 + tlen
+            if "gfx950" in triple and size:
+                path = tmp_path / f"co_{len(out)}.elf"
+                path.write_bytes(blob[pos + off:pos + off + size])
+                out.append(path)
+        pos = blob.find(MAGIC, pos + len(MAGIC))
+    return out
+
+
+def _decode_kernels(tmp_path):
+    """{kernel symbol: [instruction text, ...]} for the qoa_decode_* kernels."""
+    kernels = {}
+    for co in _code_objects(tmp_path):
+        text = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", str(co)], text=True)
+        name = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+            if m:
+                name = m.group(1)
+                continue
+            if name and "qoa_decode" in name and line.strip():
+                ins = line.split("//")[0].strip()
+                if ins:
+                    kernels.setdefault(name, []).append(ins)
+    return kernels
+
+
+ACC = re.compile(r"\ba(\d+|\[\d+:\d+\])")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.skip("libqoaudio_amd.so not built")
+    k = _decode_kernels(tmp_path_factory.mktemp("disasm"))
+    assert any("qoa_decode_uniform_kernel" in n for n in k), sorted(k)
+    assert any("qoa_decode_frames_kernel" in n for n in k), sorted(k)
+    return k
+
+
+def test_accvgprs_are_touched_only_by_the_prefetch_protocol(kernels):
+    checked = 0
+    for name, ins in kernels.items():
+        for i in ins:
+            if not ACC.search(i.split(None, 1)[1] if " " in i else ""):
+                continue
+            op = i.split()[0]
+            assert op in ("global_load_dwordx2", "global_load_dwordx4", "v_accvgpr_read_b32", "ds_write2_b64"), (name, i)
+            if op.startswith("global_load"):
+                assert ACC.match(i.split(None, 1)[1]), (name, i)  # AccVGPR is the destination
+            checked += 1
+    assert checked > 100  # the protocol is in use in many template instances
+
+
+def test_prefetched_slices_are_read_only_behind_a_wait(kernels):
+    for name, ins in kernels.items():
+        waited = False  # an s_waitcnt vmcnt with no AccVGPR load issued since
+        for i in ins:
+            op = i.split()[0]
+            if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                waited = False  # (conservative: a reader must find its wait in its own straight-line run)
+            if op == "s_waitcnt" and "vmcnt" in i:
+                waited = True
+            if op.startswith("global_load") and ACC.match(i.split(None, 1)[1]):
+                waited = False
+            if op in ("v_accvgpr_read_b32", "ds_write2_b64") and ACC.search(i.split(None, 1)[1]):
+                assert waited, (name, i)
+
+
+def test_decode_kernels_do_not_spill(kernels):
+    for name, ins in kernels.items():
+        for i in ins:
+            assert not i.startswith(("scratch_", "buffer_store", "buffer_load")), (name, i)

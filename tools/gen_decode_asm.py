@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generates qoaudio_amd/csrc/qoa_decode_asm.inc (run: python tools/gen_decode_asm.py): one slice ROW of K2u (the decoder
+for uniform full frames, qoa_decode.hip) as ONE inline-asm statement per (channel count, row of the round).
+
+Why asm: K2u is bound by VALU issue (profiles/r02_*: the VALU is busy ~80 % of the kernel at the ~1.9 GHz the chip runs
+this memory-heavy kernel at), so its cost is the instruction count of the serial sample step.  hipcc's code spends
+14.4 VALU per sample (an accumulator-zeroing move per sample for v_dot2c, state shuffling around every row, a
+10-instruction range guard per row); this text spends 10 per sample + 2 for the table lookup + ~8 per row.
+
+The row, for one lane = one (frame, channel) chain (reference: decode_one_slice_per_channel, src/lib.rs:291-330):
+  bswap the slice words; scalefactor -> its row of the LDS dequant table [sf][code] = deq | (deq >> 4) << 16
+  (src/lib.rs:847-864, :822); 20 x {3-bit code -> table entry};  range guard (below);  20 x sample step:
+      p      = dot2(w01, A) + dot2(w23, B)              the 4-tap prediction on i16 pairs, i32 wrapping sum (:799-805)
+      recon  = clamp((p >> 13) + deq, -32768, 32767)    (:310)
+      w     += sign(h) * (deq >> 4)                     2 x v_pk_mad_u16 with the (+-1, +-1) pairs (:822-826)
+      B'     = (h3, recon)                              v_alignbit_b32: the next history pair (:827)
+      image  <- recon                                   ds_write_b16 (stereo..) / ds_write_b32 of the pair (mono)
+Pair ring as in K1: B_n = (h[n-2], h[n-1]) lives in R[n % 4]; step n reads A = R[(n+2) % 4], B = R[n % 4], writes
+R[(n+1) % 4]; 20 % 4 == 0 brings every ring register back to its role, so %[pa], %[pm], %[pb] are plain in/out operands.
+
+Range guard (exactness of the i16 arithmetic).  One sample moves a weight by at most ceil(mag3(sf) / 16); %[slack] is a
+lower bound of 32767 - max|w|.  A row whose 20 * ceil(mag3 / 16) (LDS table s_grow[sf]) fits the slack cannot leave
+i16: it runs and the slack shrinks by that amount.  Otherwise nothing is executed, %[flag] = 1, and the caller
+recomputes the exact slack and either re-enters with %[force] != 0 or takes the 32-bit path.
+
+Wait states the assembler does not pad inside an asm statement (gfx940/950; see tools/gen_slice_asm.py): a v_dot2 result
+needs 3 other instructions before a different VALU reads it, a packed (v_pk_*) result 1.  The step order below keeps
+them by construction (asserted by check_hazards()).
+"""
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# fixed scratch registers (clobbered): 20 table entries + temporaries
+E0 = 64                      # v64..v83: entries
+HI, LO, TAB, T, G = 84, 85, 86, 87, 88
+P, U, RC0, RC1, RT, ST = 89, 90, 91, 92, 93, 94   # RT / ST: the fourth ring slots
+CLOBBERS = list(range(64, 95))
+
+
+def ring(kind):
+    if kind == "P":
+        return ["%[pb]", f"v{RT}", "%[pa]", "%[pm]"]
+    return ["%[sb]", f"v{ST}", "%[sa]", "%[sm]"]
+
+
+def extraction():
+    L = []
+    for i in range(20):
+        p = 57 - 3 * i
+        e = f"v{E0 + i}"
+        if p >= 32:
+            L.append(f"v_bfe_u32 {e}, v{HI}, {p - 32}, 3")
+        elif p + 2 < 32:
+            L.append(f"v_bfe_u32 {e}, v{LO}, {p}, 3")
+        else:  # the code that straddles the two words
+            L.append(f"v_alignbit_b32 {e}, v{HI}, v{LO}, {p}")
+            L.append(f"v_and_b32 {e}, 7, {e}")
+        L.append(f"v_lshl_add_u32 {e}, {e}, 2, v{TAB}")
+        L.append(f"ds_read_b32 {e}, {e}")
+    return L
+
+
+def step(i, nch, row, ring_bytes):
+    R, S = ring("P"), ring("S")
+    A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
+    SA, SB = S[(i + 2) % 4], S[i % 4]
+    e = f"v{E0 + i}"
+    rc = f"v{RC0 + i % 2}"
+    L = [
+        f"v_dot2_i32_i16 v{P}, %[w01], {A}, 0",
+        f"v_dot2_i32_i16 v{P}, %[w23], {B}, v{P}",
+        f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",       # the inline 15 has no high half to select
+        f"v_pk_mad_u16 %[w01], {e}, {SA}, %[w01] op_sel:[1,0,0]",  # entry's high half (deq >> 4) feeds both lanes
+        f"v_or_b32 {SB}, %[one2], {SB}",                           # (+-1, +-1) for B
+        f"v_ashrrev_i32 v{U}, 13, v{P}",
+        f"v_add_u32_sdwa v{U}, v{U}, sext({e}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0",
+        f"v_med3_i32 {rc}, v{U}, %[lo16], %[hi16]",
+        f"v_pk_mad_u16 %[w23], {e}, {SB}, %[w23] op_sel:[1,0,0]",
+        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",                    # (h3, recon)
+    ]
+    if nch == 1:
+        if i & 1:  # consecutive samples are adjacent in a mono image: the new history pair IS the dword to store
+            off = ((row * 20 + i - 1) * 2) % ring_bytes
+            L.append(f"ds_write_b32 %[img], {Bn} offset:{off}")
+    else:
+        off = ((row * 20 + i) * nch * 2) % ring_bytes
+        L.append(f"ds_write_b16 %[img], {rc} offset:{off}")
+    return L
+
+
+def row_text(nch, row, ring_bytes):
+    L = [
+        f"v_perm_b32 v{HI}, %[rx], %[rx], %[bsw]",
+        f"v_perm_b32 v{LO}, %[ry], %[ry], %[bsw]",
+        f"v_lshrrev_b32 v{T}, 28, v{HI}",
+        f"v_lshl_add_u32 v{TAB}, v{T}, 5, %[tab]",
+        f"v_lshl_add_u32 v{T}, v{T}, 2, %[grow]",
+        f"ds_read_b32 v{G}, v{T}",
+    ]
+    L += extraction()
+    L += [
+        "s_cmp_lg_u32 %[force], 0",
+        "s_cbranch_scc1 Lqoa_go_%=",
+        "s_waitcnt lgkmcnt(15)",                      # 20 reads are younger than G's
+        f"v_cmp_lt_i32 vcc, %[slack], v{G}",
+        "s_cbranch_vccnz Lqoa_decline_%=",
+        f"v_sub_u32 %[slack], %[slack], v{G}",
+        "Lqoa_go_%=:",
+    ]
+    for i in range(20):
+        if i % 5 == 0:
+            # LDS ops retire in order; the 15 youngest at step i are its i image writes and table reads i+5..19
+            L.append("s_waitcnt lgkmcnt(15)")
+        L += step(i, nch, row, ring_bytes)
+    L += [
+        "s_mov_b32 %[flag], 0",
+        "s_branch Lqoa_end_%=",
+        "Lqoa_decline_%=:",
+        "s_waitcnt lgkmcnt(0)",                       # the scratch registers are the compiler's again after this statement
+        "s_mov_b32 %[flag], 1",
+        "Lqoa_end_%=:",
+    ]
+    return L
+
+
+_MOD = re.compile(r"\b(op_sel_hi|op_sel|offset|dst_sel|dst_unused|src0_sel|src1_sel):(\[[^\]]*\]|\S+)")
+
+
+def _regs(tok):
+    tok = tok.strip()
+    m = re.fullmatch(r"sext\((.*)\)", tok)
+    if m:
+        tok = m.group(1)
+    if re.fullmatch(r"v\d+", tok) or tok.startswith("%["):
+        return [tok]
+    return []
+
+
+def check_hazards(lines):
+    """dot2 -> other VALU read: >= 3 instructions between; packed -> VALU read: >= 1 between."""
+    last = {}
+    n = 0
+    for l in lines:
+        if not l.startswith("v_"):
+            continue  # (conservative: only VALU instructions are counted as wait states)
+        op, rest = l.split(None, 1)
+        ops = [_regs(t) for t in _MOD.sub("", rest).split(",")]
+        dst, src = ops[0], sum(ops[1:], [])
+        for r in src:
+            if r in last:
+                pop, pos = last[r]
+                if pop.startswith("v_dot2") and not (op.startswith("v_dot2") and r in ops[-1]):
+                    assert n - pos >= 4, (l, pop, n - pos)
+                if pop.startswith("v_pk_"):
+                    assert n - pos >= 2, (l, pop, n - pos)
+        for r in dst:
+            last[r] = (op, n)
+        n += 1
+
+
+def emit(name, lines):
+    return f"#define {name} \\\n" + " \\\n".join(f'    "{l}\\n\\t"' for l in lines) + "\n"
+
+
+# (channels, rows per round, image ring bytes): must agree with K2uCfg in qoa_decode.hip (static_asserts there)
+GEOMETRY = {1: (16, 256), 2: (8, 256)}
+
+
+def render():
+    out = ["// GENERATED by tools/gen_decode_asm.py -- do not edit.",
+           "// QOA_DEC_ROW_TEXT_<channels>_<row of the round>: one slice row of K2u (20 samples of every chain of the wave) on",
+           "// i16-packed weights / history; scratch v64-v94.  See the generator for operands and wait-state rules.",
+           f"#define QOA_DEC_ROW_CLOBBERS " + ", ".join(f'"v{r}"' for r in CLOBBERS),
+           "#define QOA_DEC_ASM_RING_1 %d" % GEOMETRY[1][1], "#define QOA_DEC_ASM_RING_2 %d" % GEOMETRY[2][1], ""]
+    n_lines = 0
+    for nch, (rows, ring_bytes) in GEOMETRY.items():
+        for row in range(rows):
+            t = row_text(nch, row, ring_bytes)
+            check_hazards(t)
+            n_lines = len(t)
+            out.append(emit(f"QOA_DEC_ROW_TEXT_{nch}_{row}", t))
+    return "\n".join(out), n_lines
+
+
+INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_decode_asm.inc")
+
+
+def main():
+    out, n = render()
+    with open(INC_PATH, "w") as f:
+        f.write(out)
+    print(f"wrote {INC_PATH}: {n} lines per row")
+
+
+if __name__ == "__main__":
+    main()
