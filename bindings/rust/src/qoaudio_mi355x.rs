@@ -4,6 +4,11 @@
 //! `rafaelcaricio/qoaudio` 1.0 (`src/lib.rs` of the reference; line numbers below refer to it), forwarded to
 //! the C ABI in `include/qoaudio_amd.h`.  The reference forbids unsafe code; an FFI shim cannot.
 //!
+//! Every public signature equals the reference's (`mode()` and `current_frame_header()` return references to values
+//! cached in the handle, as `src/lib.rs:180-188` do).  tests/test_rust_shim_abi.py checks the `extern "C"` block below
+//! against `include/qoaudio_amd.h` symbol by symbol (argument count, pointer depth, constness, integer width) -- the
+//! only verification possible without `rustc`.
+//!
 //! Differences a caller can observe: readers are drained eagerly in
 //! `QoaDecoder::new`; there is no CPU fallback (no usable GPU => `IoError`).
 use std::ffi::CStr;
@@ -249,13 +254,32 @@ pub fn encode_all(sample_data: &[i16], desc: &QoaDesc) -> Result<Vec<u8>, Encode
 }
 
 /// Decoder of QOA files (:47-68).  The reader is drained in `new`; the GPU decodes whole frames and `next`
-/// replays the reference's item order.
+/// replays the reference's item order.  `mode` and `current_frame` mirror the reference's fields of the same purpose
+/// (:60, :63) so that the accessors can hand out references.
 #[derive(Debug)]
 pub struct QoaDecoder<R> {
     h: *mut ffi::qoa_decoder,
     reader: Option<R>,
+    mode: ProcessingMode,
+    current_frame: FrameHeader,
 }
 unsafe impl<R: Send> Send for QoaDecoder<R> {}
+
+fn query_mode(h: *mut ffi::qoa_decoder) -> ProcessingMode {
+    let mut m = ffi::qoa_mode::default();
+    unsafe { ffi::qoa_decoder_mode(h, &mut m) };
+    if m.kind == 1 {
+        ProcessingMode::Streaming
+    } else {
+        ProcessingMode::FixedSamples { channels: m.channels, sample_rate: m.sample_rate, samples: m.samples }
+    }
+}
+
+fn query_header(h: *mut ffi::qoa_decoder) -> FrameHeader {
+    let mut fh = ffi::qoa_frame_header::default();
+    unsafe { ffi::qoa_decoder_current_frame_header(h, &mut fh) };
+    FrameHeader { num_channels: fh.num_channels, sample_rate: fh.sample_rate, num_samples_per_channel: fh.num_samples_per_channel }
+}
 
 impl<R: io::Read> QoaDecoder<R> {
     pub fn new(mut reader: R) -> Result<Self, DecodeError> { // :127-169
@@ -263,25 +287,13 @@ impl<R: io::Read> QoaDecoder<R> {
         reader.read_to_end(&mut bytes)?;
         let mut h = std::ptr::null_mut();
         match unsafe { ffi::qoa_decoder_new(bytes.as_ptr(), bytes.len(), &mut h) } {
-            0 => Ok(Self { h, reader: Some(reader) }),
+            0 => Ok(Self { h, reader: Some(reader), mode: query_mode(h), current_frame: query_header(h) }),
             c => Err(dec_err(c)),
         }
     }
     pub fn into_inner(mut self) -> R { self.reader.take().unwrap() } // :172-174
-    pub fn mode(&self) -> ProcessingMode { // :180-182 (returned by value)
-        let mut m = ffi::qoa_mode::default();
-        unsafe { ffi::qoa_decoder_mode(self.h, &mut m) };
-        if m.kind == 1 {
-            ProcessingMode::Streaming
-        } else {
-            ProcessingMode::FixedSamples { channels: m.channels, sample_rate: m.sample_rate, samples: m.samples }
-        }
-    }
-    pub fn current_frame_header(&self) -> FrameHeader { // :186-188 (returned by value)
-        let mut h = ffi::qoa_frame_header::default();
-        unsafe { ffi::qoa_decoder_current_frame_header(self.h, &mut h) };
-        FrameHeader { num_channels: h.num_channels, sample_rate: h.sample_rate, num_samples_per_channel: h.num_samples_per_channel }
-    }
+    pub fn mode(&self) -> &ProcessingMode { &self.mode } // :180-182
+    pub fn current_frame_header(&self) -> &FrameHeader { &self.current_frame } // :186-188
     pub fn total_duration(&self) -> Option<Duration> { // :190-201
         let d = unsafe { ffi::qoa_decoder_total_duration(self.h) };
         if d < 0.0 { None } else { Some(Duration::from_secs_f64(d)) }
@@ -299,7 +311,8 @@ impl QoaDecoder<Cursor<Vec<u8>>> {
     pub fn new_streaming() -> Result<Self, DecodeError> { // :632-638
         let mut h = std::ptr::null_mut();
         match unsafe { ffi::qoa_decoder_new_streaming(&mut h) } {
-            0 => Ok(Self { h, reader: Some(Cursor::new(Vec::new())) }),
+            0 => Ok(Self { h, reader: Some(Cursor::new(Vec::new())), mode: ProcessingMode::Streaming,
+                           current_frame: FrameHeader::default() }),
             c => Err(dec_err(c)),
         }
     }
@@ -308,6 +321,7 @@ impl QoaDecoder<Cursor<Vec<u8>>> {
         let rc = unsafe {
             ffi::qoa_decoder_decode_frame(self.h, frame_data.as_ptr(), frame_data.len(), std::ptr::null_mut(), 0, &mut n)
         };
+        self.current_frame = query_header(self.h); // the frames just consumed moved it (:246-289)
         if n == 0 {
             return if rc != 0 { Err(dec_err(rc)) } else { Ok(Vec::new()) };
         }
@@ -325,11 +339,15 @@ impl<R: io::Read> Iterator for QoaDecoder<R> { // :661-693
         unsafe { ffi::qoa_decoder_next(self.h, &mut it) };
         match it.kind {
             0 => Some(Ok(QoaItem::Sample(it.sample))),
-            1 => Some(Ok(QoaItem::FrameHeader(FrameHeader {
-                num_channels: it.header.num_channels,
-                sample_rate: it.header.sample_rate,
-                num_samples_per_channel: it.header.num_samples_per_channel,
-            }))),
+            1 => {
+                // the reference updates current_frame.header in the call that parses the header (:246-289, :683-686)
+                self.current_frame = FrameHeader {
+                    num_channels: it.header.num_channels,
+                    sample_rate: it.header.sample_rate,
+                    num_samples_per_channel: it.header.num_samples_per_channel,
+                };
+                Some(Ok(QoaItem::FrameHeader(self.current_frame)))
+            }
             2 => None,
             _ => Some(Err(dec_err(it.error))),
         }

@@ -181,6 +181,19 @@ def encode_slice(history, weights, pcm, search=EXHAUSTIVE):
     return s, sf.value, (list(best.history), list(best.weights)), list(totals)
 
 
+def slice_rank_terms(history, weights, pcm):
+    """All 16 candidates of one slice run to the end: (err_sq[16], pen_sq[16], first_err_sq[16], first_pen_sq[16]);
+    a candidate's rank is err_sq + pen_sq (src/lib.rs:576)."""
+    entry = Lms((C.c_int32 * 4)(*history), (C.c_int32 * 4)(*weights))
+    a, p = _pcm(pcm)
+    arrs = [(C.c_uint64 * 16)() for _ in range(4)]
+    L = lib()
+    L.oq_slice_rank_terms.argtypes = [C.POINTER(Lms), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t] + [C.c_void_p] * 4
+    L.oq_slice_rank_terms.restype = None
+    L.oq_slice_rank_terms(C.byref(entry), p, 0, a.size, 1, *arrs)
+    return tuple(list(x) for x in arrs)
+
+
 def decode_all(data):
     """decode_all(reader) -> (channels, sample_rate, int16 ndarray)  (src/lib.rs:713-747)."""
     buf = np.frombuffer(bytes(data), dtype=np.uint8)

@@ -212,6 +212,28 @@ uint64_t oq_encode_slice(const oq_lms *entry, const int16_t *pcm, size_t start, 
     return best_slice;
 }
 
+/* Instrumentation for the pin report (oracle/README.md): every candidate of one slice run to the end, with the two
+ * terms of its rank (src/lib.rs:576) kept apart -- sum of err^2, sum of penalty^2 -- and the same for its first sample. */
+void oq_slice_rank_terms(const oq_lms *entry, const int16_t *pcm, size_t start, size_t end, size_t stride,
+                         uint64_t err_sq[16], uint64_t pen_sq[16], uint64_t first_err_sq[16], uint64_t first_pen_sq[16]) {
+    int32_t samples[OQ_SLICE_LEN];
+    int slice_len = 0;
+    for (size_t si = start; si < end && slice_len < OQ_SLICE_LEN; si += stride) samples[slice_len++] = pcm[si];
+    for (int sf = 0; sf < 16; sf++) {
+        oq_lms l = *entry;
+        uint64_t s = (uint64_t)sf;
+        err_sq[sf] = pen_sq[sf] = first_err_sq[sf] = first_pen_sq[sf] = 0;
+        for (int i = 0; i < slice_len; i++) {
+            uint64_t pen;
+            (void)lms_predict_and_penalty_sq(&l, &pen);
+            uint64_t r = candidate_step(&l, samples[i], sf, &s);
+            err_sq[sf] += r - pen;
+            pen_sq[sf] += pen;
+            if (i == 0) { first_err_sq[sf] = r - pen; first_pen_sq[sf] = pen; }
+        }
+    }
+}
+
 /* src/lib.rs:335-361 */
 int oq_encoder_init(oq_encoder *e, const oq_desc *d, int search) {
     if (d->channels == 0 || d->channels > OQ_MAX_CHANNELS) return OQ_ENC_INVALID_CHANNELS;

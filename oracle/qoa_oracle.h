@@ -92,6 +92,11 @@ uint64_t oq_encode_slice(const oq_lms *entry, const int16_t *pcm, size_t start, 
                          size_t stride, int search, int *best_sf, oq_lms *best_lms,
                          uint64_t *total_rank_out, uint64_t *steps);
 
+/* instrumentation (oracle/README.md "what the fixture pins"): per-candidate rank terms of one slice, all 16 candidates
+ * run to the end; rank = err_sq + pen_sq (src/lib.rs:576) */
+void oq_slice_rank_terms(const oq_lms *entry, const int16_t *pcm, size_t start, size_t end, size_t stride,
+                         uint64_t err_sq[16], uint64_t pen_sq[16], uint64_t first_err_sq[16], uint64_t first_pen_sq[16]);
+
 /* ---- decoder: src/lib.rs:59-68, 127-330, 627-693 ---- */
 
 /* FrameHeader, src/lib.rs:774-781 */

@@ -304,7 +304,11 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
                       clips[i].out_offset - clips[i - 1].out_offset == clips[1].out_offset - clips[0].out_offset;
         }
     }
-    uniform = uniform && n_clips > 1;
+    // the 2-D copies below take the offset differences as pitches: they must be ascending and at least a row wide
+    // (equally spaced DESCENDING offsets, or overlapping rows, pass the equal-difference test above as well)
+    uniform = uniform && n_clips > 1 && clips[1].pcm_offset > clips[0].pcm_offset && clips[1].out_offset > clips[0].out_offset &&
+              clips[1].pcm_offset - clips[0].pcm_offset >= (uint64_t)clips[0].desc.samples * clips[0].desc.channels &&
+              clips[1].out_offset - clips[0].out_offset >= qoa_encoded_size(clips[0].desc.channels, clips[0].desc.samples);
 
     HostPipe P;
     HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking), QOA_ENCODE_IO_ERROR);

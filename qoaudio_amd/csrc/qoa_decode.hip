@@ -329,7 +329,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
             for (int i = 0; i < 20; i++) entry[i] = deq_row[(unsigned)(slice >> (57 - 3 * i)) & 7u];
             // the largest weight step this row's scalefactor allows: |(-mag3) >> 4| = ceil(mag3 / 16), the code-7 entry
             const int dmax = -((int)deq_row[7] >> 16);
-            const bool row_ok = packed && dec_weights_within(pk, 32767 - 20 * dmax);
+            // lanes without a frame, and lanes past their frame's last row, decode a borrowed slice whose result is never
+            // stored: they must not vote the wave onto the 32-bit step
+            const bool live = valid && row0 + (unsigned)r < rows;
+            const bool row_ok = !live || (packed && dec_weights_within(pk, 32767 - 20 * dmax));
             if (__builtin_amdgcn_ballot_w64(!row_ok) == 0ull) {
                 // pair ring as in K1: B_i = (h[i-2], h[i-1]) lives in P[i % 4]; step i reads P[(i+2)%4] and P[i%4]
                 unsigned P[4] = {pk.pb, 0u, pk.pa, pk.pm}, S[4] = {pk.sb, 0u, pk.sa, pk.sm};

@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 if (j < kBlockSlices) {
                     const unsigned j0 = j;
                     j += run_block_pk(tile0 + 80u * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
-                    if (j < kBlockSlices && stats && sf == 0) atomicAdd(&stats[0], 1ull); // declined: see the slice loop
+                    // (a decline found here is counted once, by the slice loop below, which evaluates slice j again)
                 }
             }
             if (spec_cooldown) spec_cooldown--;

@@ -79,3 +79,17 @@ def test_two_rank_shard_and_gather(oracle, n_clips):
     for i in range(n_clips):
         x = rng_pcm(1000 + i, samples * channels)
         assert out[i].tobytes() == oracle.encode_all(x, channels, 44100, samples)
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without a launcher starts its own rank processes -- but only after checking, without
+    initialising any device, that N GPUs exist.  On this CPU-only box that check must fail fast and loudly."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    assert r.returncode == 2
+    assert "only" in r.stderr and "GPU" in r.stderr
+    assert r.stdout.strip() == ""

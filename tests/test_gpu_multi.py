@@ -1,0 +1,33 @@
+"""BASELINE config 4 (clips sharded one block per GPU, RCCL gather of the encoded buffers) through the HIP path on real
+devices.  Needs >= 2 GPUs on the box and skips otherwise (the round's GPU test box has one; the N > 1 code path is
+covered on CPU by tests/test_dist_gloo.py).  Runs bench.py exactly as a user would -- `python bench.py --gpus 2` -- so
+the launcher (one fresh rank process per GPU, started before anything touches a device) is part of what is tested."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_shard_encode_and_rccl_gather(gpu, oracle):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--clips", "64", "--frames", "8", "--no-cpu"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dist_backend"] == "nccl"
+    assert line["bit_exact_vs_oracle"] is True
+    assert line["gathered_shards_bit_exact_vs_oracle"] is True
+    assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)
+    assert line["config"]["samples_per_step"] == 2 * 64 * 8 * 5120 * 2

@@ -45,6 +45,44 @@ def test_kat1_fixture_fixed_point(oracle, fixture_bytes, fixture_pcm, search):
     assert int(np.nonzero(a != b)[0][0]) == KAT1_PREFIX  # frame 259, slice row 156, channel 0
 
 
+def test_kat1_prefix_penalty_coverage(oracle, fixture_pcm):
+    """How much of the weights-penalty path (src/lib.rs:814-817, :576) the reference-produced bytes of KAT-1 reach: the
+    numbers quoted in oracle/README.md.  Every slice inside the pinned prefix is walked with all 16 candidates run to the
+    end and the two rank terms kept apart."""
+    ch = 2
+    pcm = fixture_pcm.reshape(-1, ch)
+    n = pcm.shape[0]
+    state = [([0, 0, 0, 0], [0, 0, -8192, 16384]) for _ in range(ch)]
+    slices = pen_winner = pen_any = decided = tied = 0
+    pos, done = 8, False
+    for f0 in range(0, n, 5120):
+        fl = min(5120, n - f0)
+        pos += 8 + 16 * ch
+        for r0 in range(0, fl, 20):
+            for c in range(ch):
+                if pos + 8 > KAT1_PREFIX:
+                    done = True
+                    break
+                seg = np.ascontiguousarray(pcm[f0 + r0:f0 + min(r0 + 20, fl), c])
+                h, w = state[c]
+                e, p, fe, fp = oracle.slice_rank_terms(h, w, seg)
+                tot = [e[i] + p[i] for i in range(16)]
+                win = min(range(16), key=lambda i: (tot[i], fe[i] + fp[i], i))
+                _, sf, state[c], _ = oracle.encode_slice(h, w, seg, oracle.REF_STYLE)
+                assert sf == win
+                slices += 1
+                pen_winner += p[win] > 0
+                pen_any += any(p)
+                decided += min(range(16), key=lambda i: (e[i], fe[i], i)) != win
+                tied += sum(1 for i in range(16) if tot[i] == tot[win]) > 1
+                pos += 8
+            if done:
+                break
+        if done:
+            break
+    assert (slices, pen_winner, pen_any, decided, tied) == (132920, 866, 1022, 0, 0)
+
+
 def test_kat2_slice_search(oracle):
     s, sf, (hist, weights), totals = oracle.encode_slice(
         [-2655, -1631, -965, -806], [-5363, 11763, -15085, 16783],

@@ -25,7 +25,7 @@ for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'qoa_' not in k: continue
-        name = 'encode' if 'encode' in k else ('decode_frames' if 'frames' in k else 'decode_generic')
+        name = 'encode' if 'encode' in k else ('decode_uniform' if 'uniform' in k else ('decode_frames' if 'frames' in k else 'decode_generic'))
         agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
 with open(out + '/summary.txt', 'w') as fo:
     for k, d in agg.items():
