@@ -166,6 +166,25 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
 int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
                           uint32_t chunk_frames);
 
+/* The same pipeline as a persistent handle: its three streams, six events and device staging buffers are created once
+ * and kept (buffers grow on demand), so repeated batches stop paying that set-up.  One caller at a time per handle;
+ * every call is synchronous on return.  qoa_host_pipeline_encode == qoa_encode_batch_host; qoa_host_pipeline_decode is
+ * the decode counterpart: clips[i].out_offset locates clip i's QOA stream (as encode wrote it: 8-byte file header +
+ * frames) in h_enc, clips[i].pcm_offset its int16 PCM in h_pcm; frames [j*F, (j+1)*F) of all clips are one launch of the
+ * decode kernels, overlapped with the copy-in of the next and the copy-out of the previous slice (2 bytes per sample
+ * back over PCIe: that copy is the bound).  Every frame header is checked on the device against the clip's desc:
+ * a mismatch anywhere returns QOA_DECODE_INVALID_FRAME_HEADER.  Decode entry points return QOA_DECODE_* codes. */
+typedef struct qoa_host_pipeline qoa_host_pipeline;
+int qoa_host_pipeline_create(qoa_host_pipeline **out);
+void qoa_host_pipeline_free(qoa_host_pipeline *p);
+int qoa_host_pipeline_encode(qoa_host_pipeline *p, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm,
+                             uint8_t *h_out, uint32_t chunk_frames);
+int qoa_host_pipeline_decode(qoa_host_pipeline *p, const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc,
+                             int16_t *h_pcm, uint32_t chunk_frames);
+/* one-shot form of qoa_host_pipeline_decode */
+int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc, int16_t *h_pcm,
+                          uint32_t chunk_frames);
+
 /* ================================================================== decoder */
 
 /* FrameHeader, src/lib.rs:774-781 */

@@ -18,7 +18,8 @@ SYMBOLS = [
     "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
     "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_encode_all",
     "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_stats",
-    "qoa_encode_batch_host",
+    "qoa_encode_batch_host", "qoa_host_pipeline_create", "qoa_host_pipeline_free", "qoa_host_pipeline_encode",
+    "qoa_host_pipeline_decode", "qoa_decode_batch_host",
     "qoa_decoder_new", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
     "qoa_decoder_current_frame_header", "qoa_decoder_total_duration", "qoa_decoder_next",
     "qoa_decoder_read_samples", "qoa_decoder_decode_frame", "qoa_decode_all",
@@ -107,6 +108,12 @@ def lib():
     L.qoa_encode_plan_run.argtypes = [vp, vp, vp, vp]
     L.qoa_encode_plan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]
+    L.qoa_decode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]
+    L.qoa_host_pipeline_create.argtypes = [C.POINTER(vp)]
+    L.qoa_host_pipeline_free.argtypes = [vp]
+    L.qoa_host_pipeline_free.restype = None
+    L.qoa_host_pipeline_encode.argtypes = [vp, C.POINTER(Clip), sz, vp, vp, C.c_uint32]
+    L.qoa_host_pipeline_decode.argtypes = [vp, C.POINTER(Clip), sz, vp, vp, C.c_uint32]
     L.qoa_decoder_new.argtypes = [vp, sz, C.POINTER(vp)]
     L.qoa_decoder_new_streaming.argtypes = [C.POINTER(vp)]
     L.qoa_decoder_free.argtypes = [vp]

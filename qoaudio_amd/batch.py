@@ -185,6 +185,61 @@ def encode_batch_host(pcm: torch.Tensor, clips: Sequence[Tuple[int, int, QoaDesc
         raise EncodeError(rc)
 
 
+def _host_args(pcm: torch.Tensor, enc: torch.Tensor):
+    if pcm.is_cuda or enc.is_cuda:
+        raise ValueError("the host pipeline takes host tensors; use EncodePlan / DecodePlan for device tensors")
+    if pcm.dtype != torch.int16 or enc.dtype != torch.uint8 or not pcm.is_contiguous() or not enc.is_contiguous():
+        raise ValueError("pcm must be contiguous int16 and the encoded buffer contiguous uint8")
+
+
+def decode_batch_host(enc: torch.Tensor, clips: Sequence[Tuple[int, int, QoaDesc]], pcm: torch.Tensor,
+                      chunk_frames: int = 0) -> None:
+    """Host-memory batch decode through the frame-sliced pipeline (qoa_decode_batch_host): the inverse of
+    encode_batch_host with the same clip list (out_offset locates a clip's QOA stream in `enc`, pcm_offset its PCM)."""
+    _host_args(pcm, enc)
+    arr = _clips_array(clips)
+    rc = _lib.lib().qoa_decode_batch_host(arr, len(clips), C.c_void_p(enc.data_ptr()), C.c_void_p(pcm.data_ptr()),
+                                          chunk_frames)
+    if rc:
+        raise DecodeError(rc)
+
+
+class HostPipeline:
+    """Persistent form of encode_batch_host / decode_batch_host: streams, events and device staging buffers are created
+    once and reused by every call (qoa_host_pipeline_*)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(None)
+        rc = _lib.lib().qoa_host_pipeline_create(C.byref(self._h))
+        if rc:
+            self._h = None
+            raise EncodeError(rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().qoa_host_pipeline_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def encode(self, pcm: torch.Tensor, clips, out: torch.Tensor, chunk_frames: int = 0) -> None:
+        _host_args(pcm, out)
+        arr = _clips_array(clips)
+        rc = _lib.lib().qoa_host_pipeline_encode(self._h, arr, len(clips), C.c_void_p(pcm.data_ptr()),
+                                                 C.c_void_p(out.data_ptr()), chunk_frames)
+        if rc:
+            raise EncodeError(rc)
+
+    def decode(self, enc: torch.Tensor, clips, pcm: torch.Tensor, chunk_frames: int = 0) -> None:
+        _host_args(pcm, enc)
+        arr = _clips_array(clips)
+        rc = _lib.lib().qoa_host_pipeline_decode(self._h, arr, len(clips), C.c_void_p(enc.data_ptr()),
+                                                 C.c_void_p(pcm.data_ptr()), chunk_frames)
+        if rc:
+            raise DecodeError(rc)
+
+
 def decode_batch(enc: torch.Tensor, desc: QoaDesc) -> torch.Tensor:
     """enc: uint8 device tensor [n_clips, encoded_size] as encode_batch wrote it -> int16 [n, samples, channels]."""
     n = enc.shape[0]

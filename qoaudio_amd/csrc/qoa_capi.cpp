@@ -259,26 +259,31 @@ extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_s
 // frames [j*F, (j+1)*F) of ALL clips are one launch that still fills the chip, while the copy engines move
 // slice j+1 in and slice j-1 out.  Output bytes are identical to encode_all per clip.
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct HostPipe {
+struct qoa_host_pipeline {
     hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
     hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
-    DevBuf pcm[2], enc[2], chains[2], lms;
-    ~HostPipe() {
-        for (int i = 0; i < 2; i++) {
-            if (in_done[i]) (void)hipEventDestroy(in_done[i]);
-            if (k_done[i]) (void)hipEventDestroy(k_done[i]);
-            if (out_done[i]) (void)hipEventDestroy(out_done[i]);
+    DevBuf pcm[2], enc[2], chains[2], lms; // device staging, grown on demand and kept between calls
+    struct DecTablesHolder *dec = nullptr;  // decode tables (two sets), defined further down
+    bool ready = false;
+    hipError_t init() {
+        if (ready) return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e == hipSuccess; b++) {
+            e = hipEventCreateWithFlags(&in_done[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&k_done[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&out_done[b], hipEventDisableTiming);
         }
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_k) (void)hipStreamDestroy(s_k);
-        if (s_out) (void)hipStreamDestroy(s_out);
+        ready = (e == hipSuccess);
+        return e;
     }
+    ~qoa_host_pipeline();
 };
-} // namespace
+typedef qoa_host_pipeline HostPipe;
 
-extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
-                                     uint32_t chunk_frames) {
+static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
+                            uint32_t chunk_frames) {
     if (!clips || !h_pcm || !h_out) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
     if (n_clips == 0) return QOA_OK;
     uint32_t max_frames = 0;
@@ -310,16 +315,10 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
               clips[1].pcm_offset - clips[0].pcm_offset >= (uint64_t)clips[0].desc.samples * clips[0].desc.channels &&
               clips[1].out_offset - clips[0].out_offset >= qoa_encoded_size(clips[0].desc.channels, clips[0].desc.samples);
 
-    HostPipe P;
-    HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking), QOA_ENCODE_IO_ERROR);
-    HIP_TRY(hipStreamCreateWithFlags(&P.s_k, hipStreamNonBlocking), QOA_ENCODE_IO_ERROR);
-    HIP_TRY(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(P.init(), QOA_ENCODE_IO_ERROR);
     size_t n_chains_total = 0;
     for (size_t i = 0; i < n_clips; i++) n_chains_total += clips[i].desc.channels;
     for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipEventCreateWithFlags(&P.in_done[b], hipEventDisableTiming), QOA_ENCODE_IO_ERROR);
-        HIP_TRY(hipEventCreateWithFlags(&P.k_done[b], hipEventDisableTiming), QOA_ENCODE_IO_ERROR);
-        HIP_TRY(hipEventCreateWithFlags(&P.out_done[b], hipEventDisableTiming), QOA_ENCODE_IO_ERROR);
         HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_ENCODE_IO_ERROR);
         HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_ENCODE_IO_ERROR);
         HIP_TRY(P.chains[b].reserve(n_chains_total * sizeof(EncChain)), QOA_ENCODE_IO_ERROR);
@@ -428,6 +427,32 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
     HIP_TRY(hipStreamSynchronize(P.s_out), QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipStreamSynchronize(P.s_k), QOA_ENCODE_IO_ERROR);
     return QOA_OK;
+}
+
+extern "C" int qoa_host_pipeline_create(qoa_host_pipeline **out) {
+    if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
+    *out = nullptr;
+    auto *p = new (std::nothrow) qoa_host_pipeline();
+    if (!p) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
+    hipError_t e = p->init();
+    if (e != hipSuccess) { delete p; return fail_hip(e, "qoa_host_pipeline_create", QOA_ENCODE_IO_ERROR); }
+    *out = p;
+    return QOA_OK;
+}
+
+extern "C" void qoa_host_pipeline_free(qoa_host_pipeline *p) { delete p; }
+
+extern "C" int qoa_host_pipeline_encode(qoa_host_pipeline *p, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm,
+                                        uint8_t *h_out, uint32_t chunk_frames) {
+    if (!p) return fail_msg("null pipeline", QOA_ENCODE_IO_ERROR);
+    return host_pipe_encode(*p, clips, n_clips, h_pcm, h_out, chunk_frames);
+}
+
+// one-shot form: a pipeline that lives for one call (streams, events and staging buffers are set up and torn down)
+extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
+                                     uint32_t chunk_frames) {
+    qoa_host_pipeline P;
+    return host_pipe_encode(P, clips, n_clips, h_pcm, h_out, chunk_frames);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,8 +672,14 @@ struct DecTables {
     unsigned n_chains = 0;
     DevBuf mismatch;
 
-    hipError_t upload(const std::vector<DecChain> &recs, hipStream_t stream) {
-        std::vector<DecChain> per[kMaxChannels + 1], generic;
+    // host copies of what upload() sends: they are the sources of asynchronous copies and live until the next upload
+    std::vector<DecChain> per[kMaxChannels + 1], generic, uni[3];
+
+    // sync = false: the copies are only enqueued on `stream`; the caller must not call upload() again before they ran
+    hipError_t upload(const std::vector<DecChain> &recs, hipStream_t stream, bool sync = true) {
+        for (auto &v : per) v.clear();
+        for (auto &v : uni) v.clear();
+        generic.clear();
         for (const DecChain &d : recs) {
             if (d.rows == 0 || d.n_out == 0) continue;
             if (d.channels <= kMaxChannels) per[d.channels].push_back(d);
@@ -659,7 +690,6 @@ struct DecTables {
                 generic.push_back(e);
             }
         }
-        std::vector<DecChain> uni[3];
         for (int n = 1; n <= 2; n++) {
             std::vector<DecChain> rest;
             for (const DecChain &d : per[n]) {
@@ -671,8 +701,9 @@ struct DecTables {
             uni[n].resize(keep);
             per[n].swap(rest);
         }
+        const bool fresh = mismatch.p == nullptr;
         hipError_t e = mismatch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
-        if (e == hipSuccess) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
+        if (e == hipSuccess && (fresh || sync)) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
         for (int n = 1; n <= 2 && e == hipSuccess; n++) {
             n_uframes[n] = (unsigned)uni[n].size();
             if (uni[n].empty()) continue;
@@ -695,7 +726,7 @@ struct DecTables {
             if (e == hipSuccess)
                 e = hipMemcpyAsync(chains.p, generic.data(), generic.size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(stream); // the host vectors above die with this call
+        if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
         return e;
     }
     bool empty() const {
@@ -703,9 +734,11 @@ struct DecTables {
         for (int n = 1; n <= kMaxChannels; n++) if (n_frames[n]) return false;
         return true;
     }
-    hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream) {
-        hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream); // the count is per run
-        if (e0 != hipSuccess) return e0;
+    hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream, bool reset_mismatches = true) {
+        if (reset_mismatches) { // the count is per run (the host pipeline lets it add up over its time slices)
+            hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
+            if (e0 != hipSuccess) return e0;
+        }
         for (int n = 1; n <= 2; n++) {
             if (!n_uframes[n]) continue;
             // K2u stores 16-byte pieces at frame offsets that are multiples of 16: with an odd base pointer (a caller's
@@ -901,6 +934,182 @@ extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count
     HIP_TRY(hipDeviceSynchronize(), QOA_DECODE_IO_ERROR);
     HIP_TRY(hipMemcpy(count, plan->t.mismatch.p, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
     return QOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-memory batch decode: frame-sliced pipeline (the decode half)
+//
+// Decode frames are independent (the LMS state is re-seeded from every frame header, src/lib.rs:270-281), so the batch
+// is cut along time exactly like the encode pipeline but without any carried state: frames [j*F, (j+1)*F) of all clips
+// are copied in (their bytes are contiguous per clip), decoded by K2 / K2u, and their PCM copied out, the three stages of
+// neighbouring slices overlapping on three streams.  The copy out moves 2 bytes per sample over PCIe: this pipeline is
+// bound by that transfer by construction (DESIGN.md section 5 has the measured rates), not by the kernel.
+// Layout trusted like qoa_decode_plan_from_clips; every frame header is verified on the device.
+// ------------------------------------------------------------------------------------------------
+struct DecTablesHolder {
+    DecTables t[2];
+};
+
+qoa_host_pipeline::~qoa_host_pipeline() {
+    if (s_in) (void)hipStreamSynchronize(s_in);
+    if (s_k) (void)hipStreamSynchronize(s_k);
+    if (s_out) (void)hipStreamSynchronize(s_out);
+    delete dec;
+    for (int i = 0; i < 2; i++) {
+        if (in_done[i]) (void)hipEventDestroy(in_done[i]);
+        if (k_done[i]) (void)hipEventDestroy(k_done[i]);
+        if (out_done[i]) (void)hipEventDestroy(out_done[i]);
+    }
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_k) (void)hipStreamDestroy(s_k);
+    if (s_out) (void)hipStreamDestroy(s_out);
+}
+
+static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc, int16_t *h_pcm,
+                            uint32_t chunk_frames) {
+    if (!clips || !h_enc || !h_pcm) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
+    if (n_clips == 0) return QOA_OK;
+    uint32_t max_frames = 0;
+    for (size_t i = 0; i < n_clips; i++) {
+        if (validate_desc(&clips[i].desc)) return fail_msg("invalid qoa_desc in decode batch", QOA_DECODE_INVALID_FRAME_HEADER);
+        max_frames = std::max<uint32_t>(max_frames, (clips[i].desc.samples + kFrameLen - 1) / kFrameLen);
+    }
+    const uint32_t F = chunk_frames ? chunk_frames : 8;
+    const uint32_t n_chunks = (max_frames + F - 1) / F;
+    HIP_TRY(P.init(), QOA_DECODE_IO_ERROR);
+    if (!P.dec) P.dec = new (std::nothrow) DecTablesHolder();
+    if (!P.dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+
+    // device staging per buffer: per clip F frames of encoded bytes and F frames of PCM
+    std::vector<uint64_t> pcm_reg(n_clips + 1, 0), enc_reg(n_clips + 1, 0);
+    bool uniform = n_clips > 1;
+    for (size_t i = 0; i < n_clips; i++) {
+        const qoa_desc &d = clips[i].desc;
+        pcm_reg[i + 1] = pcm_reg[i] + (uint64_t)F * kFrameLen * d.channels;                          // int16 elements
+        enc_reg[i + 1] = enc_reg[i] + (uint64_t)F * qoa_frame_size(d.channels, kSlicesPerFrame);     // bytes, 8-aligned
+        if (i > 0) {
+            const qoa_desc &q = clips[i - 1].desc;
+            uniform = uniform && d.channels == q.channels && d.samples == q.samples &&
+                      clips[i].pcm_offset - clips[i - 1].pcm_offset == clips[1].pcm_offset - clips[0].pcm_offset &&
+                      clips[i].out_offset - clips[i - 1].out_offset == clips[1].out_offset - clips[0].out_offset;
+        }
+    }
+    uniform = uniform && clips[1].pcm_offset > clips[0].pcm_offset && clips[1].out_offset > clips[0].out_offset &&
+              clips[1].pcm_offset - clips[0].pcm_offset >= (uint64_t)clips[0].desc.samples * clips[0].desc.channels &&
+              clips[1].out_offset - clips[0].out_offset >= qoa_encoded_size(clips[0].desc.channels, clips[0].desc.samples);
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_DECODE_IO_ERROR);
+        HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_DECODE_IO_ERROR);
+    }
+    // what time slice j holds of clip d: frames, encoded bytes (whole frames, the last one possibly short), sample-times
+    auto slice_of = [&](const qoa_desc &d, uint32_t j, uint64_t *enc_off, uint64_t *enc_bytes, uint64_t *first, uint64_t *now) {
+        *first = (uint64_t)j * F * kFrameLen;
+        *now = d.samples > *first ? std::min<uint64_t>(d.samples - *first, (uint64_t)F * kFrameLen) : 0;
+        const uint64_t fb = qoa_frame_size(d.channels, kSlicesPerFrame);
+        const uint64_t full = *now / kFrameLen, rest = *now % kFrameLen;
+        *enc_off = 8 + (uint64_t)j * F * fb;
+        *enc_bytes = full * fb + (rest ? qoa_frame_size(d.channels, (uint32_t)((rest + kSliceLen - 1) / kSliceLen)) : 0);
+    };
+    bool first_upload[2] = {true, true};
+    std::vector<DecChain> recs;
+    for (uint32_t j = 0; j < n_chunks + 1; j++) {
+        const int b = (int)(j & 1u);
+        if (j < n_chunks) {
+            DecTables &T = P.dec->t[b];
+            // ---- stage in: encoded frames of time slice j (buffer b is free once the kernel of slice j-2 has run) ----
+            if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_in, P.k_done[b], 0), QOA_DECODE_IO_ERROR);
+            recs.clear();
+            for (size_t i = 0; i < n_clips; i++) {
+                const qoa_desc &d = clips[i].desc;
+                uint64_t eo, eb, first, now;
+                slice_of(d, j, &eo, &eb, &first, &now);
+                if (!now) continue;
+                if (!uniform)
+                    HIP_TRY(hipMemcpyAsync((uint8_t *)P.enc[b].p + enc_reg[i], h_enc + clips[i].out_offset + eo, eb,
+                                           hipMemcpyHostToDevice, P.s_in), QOA_DECODE_IO_ERROR);
+                uint64_t pos = enc_reg[i], outp = pcm_reg[i], left = now;
+                while (left > 0) {
+                    const uint32_t fl = (uint32_t)std::min<uint64_t>(left, kFrameLen);
+                    const uint32_t rows = (fl + kSliceLen - 1) / kSliceLen;
+                    const uint32_t fsize = qoa_frame_size(d.channels, rows);
+                    DecChain dc;
+                    dc.frame_off = pos; dc.out_off = outp; dc.n_out = fl; dc.rows = (uint16_t)rows;
+                    dc.channels = d.channels; dc.channel = 0;
+                    dc.expect_hi = ((uint32_t)d.channels << 24) | d.sample_rate;
+                    dc.expect_lo = (fl << 16) | fsize;
+                    recs.push_back(dc);
+                    pos += fsize; outp += (uint64_t)fl * d.channels; left -= fl;
+                }
+            }
+            if (uniform) {
+                uint64_t eo, eb, first, now;
+                slice_of(clips[0].desc, j, &eo, &eb, &first, &now);
+                HIP_TRY(hipMemcpy2DAsync(P.enc[b].p, enc_reg[1] - enc_reg[0], h_enc + clips[0].out_offset + eo,
+                                         clips[1].out_offset - clips[0].out_offset, eb, n_clips, hipMemcpyHostToDevice, P.s_in),
+                        QOA_DECODE_IO_ERROR);
+            }
+            HIP_TRY(T.upload(recs, P.s_in, false), QOA_DECODE_IO_ERROR);
+            if (first_upload[b]) { // the mismatch counter adds up over the slices of this call
+                HIP_TRY(hipMemsetAsync(T.mismatch.p, 0, sizeof(unsigned), P.s_in), QOA_DECODE_IO_ERROR);
+                first_upload[b] = false;
+            }
+            HIP_TRY(hipEventRecord(P.in_done[b], P.s_in), QOA_DECODE_IO_ERROR);
+            // ---- decode time slice j (its PCM buffer is free once slice j-2 has been copied out) ----
+            HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0), QOA_DECODE_IO_ERROR);
+            if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0), QOA_DECODE_IO_ERROR);
+            HIP_TRY(T.run((const uint8_t *)P.enc[b].p, (int16_t *)P.pcm[b].p, P.s_k, false), QOA_DECODE_IO_ERROR);
+            HIP_TRY(hipEventRecord(P.k_done[b], P.s_k), QOA_DECODE_IO_ERROR);
+        }
+        if (j >= 1) {
+            // ---- stage out: PCM of time slice j-1 ----
+            const uint32_t jj = j - 1;
+            const int bo = (int)(jj & 1u);
+            HIP_TRY(hipStreamWaitEvent(P.s_out, P.k_done[bo], 0), QOA_DECODE_IO_ERROR);
+            if (uniform) {
+                uint64_t eo, eb, first, now;
+                slice_of(clips[0].desc, jj, &eo, &eb, &first, &now);
+                const qoa_desc &d = clips[0].desc;
+                HIP_TRY(hipMemcpy2DAsync(h_pcm + clips[0].pcm_offset + first * d.channels, (clips[1].pcm_offset - clips[0].pcm_offset) * 2,
+                                         P.pcm[bo].p, (pcm_reg[1] - pcm_reg[0]) * 2, now * d.channels * 2, n_clips,
+                                         hipMemcpyDeviceToHost, P.s_out), QOA_DECODE_IO_ERROR);
+            } else {
+                for (size_t i = 0; i < n_clips; i++) {
+                    const qoa_desc &d = clips[i].desc;
+                    uint64_t eo, eb, first, now;
+                    slice_of(d, jj, &eo, &eb, &first, &now);
+                    if (now)
+                        HIP_TRY(hipMemcpyAsync(h_pcm + clips[i].pcm_offset + first * d.channels, (int16_t *)P.pcm[bo].p + pcm_reg[i],
+                                               now * d.channels * 2, hipMemcpyDeviceToHost, P.s_out), QOA_DECODE_IO_ERROR);
+                }
+            }
+            HIP_TRY(hipEventRecord(P.out_done[bo], P.s_out), QOA_DECODE_IO_ERROR);
+        }
+        // the host copies of table set b are rewritten two slices later: its upload must have run by then
+        if (j < n_chunks) HIP_TRY(hipEventSynchronize(P.in_done[b]), QOA_DECODE_IO_ERROR);
+    }
+    HIP_TRY(hipStreamSynchronize(P.s_out), QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipStreamSynchronize(P.s_k), QOA_DECODE_IO_ERROR);
+    uint32_t bad = 0;
+    for (int b = 0; b < 2; b++) {
+        if (first_upload[b]) continue;
+        uint32_t m = 0;
+        HIP_TRY(hipMemcpy(&m, P.dec->t[b].mismatch.p, sizeof m, hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
+        bad += m;
+    }
+    if (bad) return fail_msg("frame headers in the batch do not match the clip descriptions", QOA_DECODE_INVALID_FRAME_HEADER);
+    return QOA_OK;
+}
+
+extern "C" int qoa_host_pipeline_decode(qoa_host_pipeline *p, const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc,
+                                        int16_t *h_pcm, uint32_t chunk_frames) {
+    if (!p) return fail_msg("null pipeline", QOA_DECODE_IO_ERROR);
+    return host_pipe_decode(*p, clips, n_clips, h_enc, h_pcm, chunk_frames);
+}
+
+extern "C" int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc, int16_t *h_pcm,
+                                     uint32_t chunk_frames) {
+    qoa_host_pipeline P;
+    return host_pipe_decode(P, clips, n_clips, h_enc, h_pcm, chunk_frames);
 }
 
 // ------------------------------------------------------------------------------------------------

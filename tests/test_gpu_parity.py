@@ -720,3 +720,63 @@ def test_degenerate_shapes(gpu, oracle):
         d = gpu.decode_all(enc)
         _, _, want = oracle.decode_all(enc)
         assert np.array_equal(d.samples, want)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_decode_pipeline_and_persistent_handle(gpu, oracle, pinned):
+    """qoa_decode_batch_host / qoa_host_pipeline_* (decode half + persistent handle): uniform batches
+    (2-D copies; full frames go through K2u, the short last frame through K2) and a ragged mixed-channel batch (per-clip
+    copies), several time slices each, against the oracle's decoder; one pipeline handle reused for encode and decode of
+    differently shaped batches; a damaged frame header is reported."""
+    from qoaudio_amd import batch
+    pipe = batch.HostPipeline()
+
+    def buf(t):
+        return t.pin_memory() if pinned else t
+
+    # uniform: 40 stereo clips of 7 frames + a tail (40 * 7 = 280 full frames: 8 whole wavefronts for K2u + a rest)
+    n, samples, ch = 40, 7 * 5120 + 1234, 2
+    desc = gpu.QoaDesc(ch, 32000, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n, desc)
+    pcm = buf(torch.from_numpy(np.stack([rng_pcm(500 + i, samples * ch) for i in range(n)])))
+    enc = buf(torch.zeros(n * per_enc, dtype=torch.uint8))
+    pipe.encode(pcm, clips, enc, chunk_frames=3)
+    back = buf(torch.zeros(n * per_pcm, dtype=torch.int16))
+    pipe.decode(enc, clips, back, chunk_frames=3)
+    for i in (0, 13, 39):
+        stream = enc[i * per_enc:(i + 1) * per_enc].numpy().tobytes()
+        assert stream == oracle.encode_all(pcm[i].numpy().reshape(-1), ch, 32000, samples)
+        _, _, want = oracle.decode_all(stream)
+        assert np.array_equal(back[i * per_pcm:(i + 1) * per_pcm].numpy(), want)
+    back2 = buf(torch.zeros(n * per_pcm, dtype=torch.int16))
+    batch.decode_batch_host(enc, clips, back2, chunk_frames=2)  # the one-shot form, another slice size
+    assert torch.equal(back2, back)
+    # ragged, same handle again: different lengths and channel counts; some clips end slices earlier than others
+    shapes = [(2, 5120 * 5 + 7), (1, 100), (3, 5120 * 2), (2, 5120 * 2 + 1), (8, 5120 * 3 + 19), (1, 5120 * 6), (2, 20)]
+    rclips, parts, po, oo = [], [], 0, 0
+    for i, (c, s) in enumerate(shapes):
+        x = rng_pcm(900 + i, s * c, "mix" if i % 2 else "white")
+        parts.append(x)
+        rclips.append((po, oo, gpu.QoaDesc(c, 44100, s)))
+        po += x.size
+        oo += gpu.encoded_size(c, s)
+    rp = buf(torch.from_numpy(np.concatenate(parts)))
+    ro = buf(torch.zeros(oo, dtype=torch.uint8))
+    pipe.encode(rp, rclips, ro, chunk_frames=2)
+    rb = buf(torch.zeros(po, dtype=torch.int16))
+    pipe.decode(ro, rclips, rb, chunk_frames=2)
+    host_enc, host_back = ro.numpy(), rb.numpy()
+    for (p0, o0, d), x in zip(rclips, parts):
+        want = oracle.encode_all(x, d.channels, d.sample_rate, d.samples)
+        assert host_enc[o0:o0 + len(want)].tobytes() == want, d
+        _, _, dec = oracle.decode_all(want)
+        assert np.array_equal(host_back[p0:p0 + x.size], dec), d
+    # a damaged frame header (sample rate byte of clip 4's second frame) is detected on the device
+    bad = ro.clone()
+    o4 = rclips[4][1]
+    bad[o4 + 8 + (8 + 16 * 8 + 8 * 256 * 8) + 2] ^= 0x40
+    with pytest.raises(gpu.DecodeError) as e:
+        pipe.decode(bad, rclips, rb, chunk_frames=2)
+    assert e.value.kind == "InvalidFrameHeader"
+    pipe.decode(ro, rclips, rb, chunk_frames=5)  # the handle is still good
+    assert np.array_equal(rb.numpy()[:parts[0].size], oracle.decode_all(host_enc[:rclips[1][1]].tobytes())[2])

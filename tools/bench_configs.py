@@ -112,4 +112,26 @@ for cf in (16, 8):
     t0 = time.perf_counter(); batch.encode_batch_host(host_pcm.view(-1), clips, host_out.view(-1), chunk_frames=cf); dt = time.perf_counter() - t0
     out[f"config3_host_pipeline_chunk{cf}"] = {"wall_ms": dt * 1e3, "samples_per_s_end_to_end": plan.samples / dt,
                                                "bytes_equal_device_path": bool(torch.equal(host_out, d_out.cpu()))}
+# persistent handle (qoa_host_pipeline_*): repeated batches without the stream / event / hipMalloc set-up, and the decode
+# half (PCIe-bound by construction: 2 bytes per sample back to the host)
+pipe = batch.HostPipeline()
+host_back = torch.empty((n_clips, samples, ch), dtype=torch.int16).pin_memory()
+pipe.encode(host_pcm.view(-1), clips, host_out.view(-1), chunk_frames=8)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); pipe.encode(host_pcm.view(-1), clips, host_out.view(-1), chunk_frames=8); ts.append(time.perf_counter() - t0)
+out["config3_host_pipeline_persistent_encode"] = {"wall_ms": [t * 1e3 for t in ts], "samples_per_s_end_to_end": plan.samples / min(ts),
+                                                  "bytes_equal_device_path": bool(torch.equal(host_out, d_out.cpu()))}
+pipe.decode(host_out.view(-1), clips, host_back.view(-1), chunk_frames=8)
+ts = []
+for cf in (8, 8, 16):
+    t0 = time.perf_counter(); pipe.decode(host_out.view(-1), clips, host_back.view(-1), chunk_frames=cf); ts.append(time.perf_counter() - t0)
+dplan = batch.DecodePlan.from_clips(clips)
+d_back = torch.empty_like(d_pcm)
+dplan.run(d_out, d_back); torch.cuda.synchronize()
+t0 = time.perf_counter(); host_back2 = d_back.cpu(); t_d2h = time.perf_counter() - t0
+out["config3_host_pipeline_decode"] = {"wall_ms_chunk8_8_16": [t * 1e3 for t in ts], "samples_per_s_end_to_end": plan.samples / min(ts),
+                                       "pcm_GBps_to_host": plan.pcm_bytes / min(ts) / 1e9,
+                                       "equals_device_path": bool(torch.equal(host_back, host_back2)),
+                                       "plain_d2h_copy_ms_pageable_dst": t_d2h * 1e3}
 print(json.dumps(out, indent=1))
