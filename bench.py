@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the 1-thread CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the K1 records outside the headline shape")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -291,6 +292,46 @@ def main():
                             "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt())}
         if dec_traffic_note:
             result["decode"]["roofline"]["traffic_note"] = dec_traffic_note
+
+    if rank == 0 and world == 1 and not args.no_extras and args.frames % 8 == 0:
+        # K1 outside the headline shape (records for DESIGN.md, not part of `value`): the same 2048 chains at 2 chains per
+        # wavefront (1024 wavefronts, one per SIMD), and a batch with a full wavefront for every SIMD several times over
+        # (8192 clips x 32 frames: the same 5.4 GB of PCM, 16384 chains = 4096 wavefronts, 4 per SIMD)
+        extras = {}
+        p2 = batch.EncodePlan(clips, batch.PLAN_CPW_2)
+        p2.run(pcm, out, stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); p2.run(pcm, out, stream); e1.record(stream)
+        torch.cuda.synchronize()
+        extras["config3_at_2_chains_per_wavefront_kernel_ms"] = e0.elapsed_time(e1)
+        del p2
+        plan.run(pcm, out, stream)  # `out` again holds the default plan's bytes (identical by construction; decode leg reads it)
+        fc_clips, fc_frames = 8 * n_clips, max(1, args.frames // 8)
+        fc_samples = fc_frames * 5120
+        fdesc = q.QoaDesc(ch, args.rate, fc_samples)
+        fclips, _, fper_enc = batch.uniform_clips(fc_clips, fdesc)
+        fpcm = pcm.view(fc_clips, fc_samples, ch)  # the same PCM bytes cut into 8x as many, 8x shorter clips
+        fout = torch.empty((fc_clips, fper_enc), dtype=torch.uint8, device=dev)
+        fplan = batch.EncodePlan(fclips)
+        fplan.run(fpcm, fout, stream)
+        torch.cuda.synchronize()
+        fms = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream); fplan.run(fpcm, fout, stream); e1.record(stream)
+            torch.cuda.synchronize()
+            fms.append(e0.elapsed_time(e1))
+        f_ms = float(np.mean(fms))
+        from oracle import oracle as O
+        f_ok = fout[fc_clips - 1].cpu().numpy().tobytes() == O.encode_all(fpcm[fc_clips - 1].cpu().numpy().reshape(-1), ch,
+                                                                          args.rate, fc_samples)
+        extras["full_chip"] = {"workload": f"{fc_clips} clips x {ch} ch x {fc_frames} frames (4 wavefronts per SIMD)",
+                               "kernel_ms_avg": f_ms, "samples_per_s": fplan.samples / (f_ms * 1e-3),
+                               "valu_issue": valu_issue(fc_clips * ch, fc_samples, f_ms), "bit_exact_vs_oracle": bool(f_ok)}
+        result["k1_extras"] = extras
+        del fplan, fout
+        torch.cuda.synchronize()
 
     if rank == 0 and world == 1 and not args.no_cpu:
         sample_clips = min(n_clips, 96)
