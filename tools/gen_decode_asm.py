@@ -5,11 +5,12 @@ for uniform full frames, qoa_decode.hip) as ONE inline-asm statement per (channe
 Why asm: K2u is bound by VALU issue (profiles/r02_*: the VALU is busy ~80 % of the kernel at the ~1.9 GHz the chip runs
 this memory-heavy kernel at), so its cost is the instruction count of the serial sample step.  hipcc's code spends
 14.4 VALU per sample (an accumulator-zeroing move per sample for v_dot2c, state shuffling around every row, a
-10-instruction range guard per row); this text spends 10 per sample + 2 for the table lookup + ~8 per row.
+10-instruction range guard per row); this text spends 10 per sample + 1.5 for the table lookup + ~8 per row.
 
 The row, for one lane = one (frame, channel) chain (reference: decode_one_slice_per_channel, src/lib.rs:291-330):
-  bswap the slice words; scalefactor -> its row of the LDS dequant table [sf][code] = deq | (deq >> 4) << 16
-  (src/lib.rs:847-864, :822); 20 x {3-bit code -> table entry};  range guard (below);  20 x sample step:
+  bswap the slice words; scalefactor -> its row of the LDS PAIR table [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
+  (src/lib.rs:847-864); 10 x {6 bits -> entry, entry >> 4 = the two weight steps of :822};  range guard (below);
+  20 x sample step:
       p      = dot2(w01, A) + dot2(w23, B)              the 4-tap prediction on i16 pairs, i32 wrapping sum (:799-805)
       recon  = clamp((p >> 13) + deq, -32768, 32767)    (:310)
       w     += sign(h) * (deq >> 4)                     2 x v_pk_mad_u16 with the (+-1, +-1) pairs (:822-826)
@@ -34,7 +35,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 # fixed scratch registers (clobbered): 20 table entries + temporaries
-E0 = 64                      # v64..v83: entries
+E0 = 64                      # v64..v73: pair-table entries (deq, deq), v74..v83: their weight steps (deq >> 4 pairs)
+D0 = 74
 HI, LO, TAB, T, G = 84, 85, 86, 87, 88
 P, U, RC0, RC1, RT, ST = 89, 90, 91, 92, 93, 94   # RT / ST: the fourth ring slots
 CLOBBERS = list(range(64, 95))
@@ -47,38 +49,47 @@ def ring(kind):
 
 
 def extraction():
+    """10 lookups per row: entry j of the PAIR table [sf][code(2j) * 8 + code(2j+1)] = deq(2j) | deq(2j+1) << 16, then the
+    two weight steps (deq >> 4, src/lib.rs:822) as one packed shift.  (One lookup per sample cost 2 VALU + 1 LDS read per
+    sample; this is 1.5 VALU + 0.5 reads.)"""
     L = []
-    for i in range(20):
-        p = 57 - 3 * i
-        e = f"v{E0 + i}"
+    for j in range(10):
+        p = 54 - 6 * j
+        e, d = f"v{E0 + j}", f"v{D0 + j}"
         if p >= 32:
-            L.append(f"v_bfe_u32 {e}, v{HI}, {p - 32}, 3")
-        elif p + 2 < 32:
-            L.append(f"v_bfe_u32 {e}, v{LO}, {p}, 3")
-        else:  # the code that straddles the two words
+            L.append(f"v_bfe_u32 {e}, v{HI}, {p - 32}, 6")
+        elif p + 5 < 32:
+            L.append(f"v_bfe_u32 {e}, v{LO}, {p}, 6")
+        else:  # the pair that straddles the two words
             L.append(f"v_alignbit_b32 {e}, v{HI}, v{LO}, {p}")
-            L.append(f"v_and_b32 {e}, 7, {e}")
+            L.append(f"v_and_b32 {e}, 63, {e}")
         L.append(f"v_lshl_add_u32 {e}, {e}, 2, v{TAB}")
         L.append(f"ds_read_b32 {e}, {e}")
     return L
+
+
+def deltas(j0, j1):
+    return [f"v_pk_ashrrev_i16 v{D0 + j}, 4, v{E0 + j} op_sel_hi:[0,1]" for j in range(j0, j1)]
 
 
 def step(i, nch, row, ring_bytes):
     R, S = ring("P"), ring("S")
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
-    e = f"v{E0 + i}"
+    e, d = f"v{E0 + i // 2}", f"v{D0 + i // 2}"
+    half = i % 2          # which half of the pair registers this sample uses
+    bcast = "op_sel:[1,0,0]" if half else "op_sel:[0,0,0] op_sel_hi:[0,1,1]"   # that half into both lanes of src0
     rc = f"v{RC0 + i % 2}"
     L = [
         f"v_dot2_i32_i16 v{P}, %[w01], {A}, 0",
         f"v_dot2_i32_i16 v{P}, %[w23], {B}, v{P}",
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",       # the inline 15 has no high half to select
-        f"v_pk_mad_u16 %[w01], {e}, {SA}, %[w01] op_sel:[1,0,0]",  # entry's high half (deq >> 4) feeds both lanes
+        f"v_pk_mad_u16 %[w01], {d}, {SA}, %[w01] {bcast}",
         f"v_or_b32 {SB}, %[one2], {SB}",                           # (+-1, +-1) for B
         f"v_ashrrev_i32 v{U}, 13, v{P}",
-        f"v_add_u32_sdwa v{U}, v{U}, sext({e}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0",
+        f"v_add_u32_sdwa v{U}, v{U}, sext({e}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{half}",
         f"v_med3_i32 {rc}, v{U}, %[lo16], %[hi16]",
-        f"v_pk_mad_u16 %[w23], {e}, {SB}, %[w23] op_sel:[1,0,0]",
+        f"v_pk_mad_u16 %[w23], {d}, {SB}, %[w23] {bcast}",
         f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",                    # (h3, recon)
     ]
     if nch == 1:
@@ -96,7 +107,7 @@ def row_text(nch, row, ring_bytes):
         f"v_perm_b32 v{HI}, %[rx], %[rx], %[bsw]",
         f"v_perm_b32 v{LO}, %[ry], %[ry], %[bsw]",
         f"v_lshrrev_b32 v{T}, 28, v{HI}",
-        f"v_lshl_add_u32 v{TAB}, v{T}, 5, %[tab]",
+        f"v_lshl_add_u32 v{TAB}, v{T}, 8, %[tab]",                 # &s_deq2[sf][0]: 64 entries of 4 bytes
         f"v_lshl_add_u32 v{T}, v{T}, 2, %[grow]",
         f"ds_read_b32 v{G}, v{T}",
     ]
@@ -104,16 +115,18 @@ def row_text(nch, row, ring_bytes):
     L += [
         "s_cmp_lg_u32 %[force], 0",
         "s_cbranch_scc1 Lqoa_go_%=",
-        "s_waitcnt lgkmcnt(15)",                      # 20 reads are younger than G's
+        "s_waitcnt lgkmcnt(10)",                      # the 10 table reads are younger than G's
         f"v_cmp_lt_i32 vcc, %[slack], v{G}",
         "s_cbranch_vccnz Lqoa_decline_%=",
         f"v_sub_u32 %[slack], %[slack], v{G}",
         "Lqoa_go_%=:",
     ]
+    # LDS ops retire in order: the table reads first, then one image write per sample (per second sample, mono)
+    L += ["s_waitcnt lgkmcnt(5)"] + deltas(0, 5)      # entries 0..4 are in (the 5 youngest reads may still be out)
     for i in range(20):
-        if i % 5 == 0:
-            # LDS ops retire in order; the 15 youngest at step i are its i image writes and table reads i+5..19
-            L.append("s_waitcnt lgkmcnt(15)")
+        if i == 8:
+            # before sample 10: everything but the youngest image writes; the table reads are all older than those
+            L += ["s_waitcnt lgkmcnt(%d)" % (4 if nch == 1 else 8)] + deltas(5, 10)
         L += step(i, nch, row, ring_bytes)
     L += [
         "s_mov_b32 %[flag], 0",

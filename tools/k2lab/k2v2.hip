@@ -465,14 +465,20 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + 12];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][FPW * SSP];
     __shared__ uint2 s_mags[16];
-    __shared__ __attribute__((aligned(32))) unsigned s_deq[16][8];
+    // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
+    __shared__ __attribute__((aligned(256))) unsigned s_deq2[16][64];
     __shared__ int s_grow[16]; // 20 * ceil(mag3(sf) / 16): the most one row can move a weight
 #if defined(K2U_PAD_LDS) && K2U_PAD_LDS > 0
     __shared__ unsigned s_pad[K2U_PAD_LDS / 4]; // occupancy tuning: sizes the block so that a chosen number fit a CU
     if (n_frames == 0xffffffffu) s_pad[threadIdx.x] = 1;
     if (n_frames == 0xfffffffeu) out[0] = (int16_t)s_pad[threadIdx.x ^ 1];
 #endif
-    init_deq_table(s_deq);
+    for (unsigned t = threadIdx.x; t < 1024; t += blockDim.x) {
+        const unsigned sf = t >> 6, a = (t >> 3) & 7u, b = t & 7u;
+        const int da = (a & 1u) ? -c_mags[sf][a >> 1] : c_mags[sf][a >> 1]; // QOA_DEQUANT_TAB, src/lib.rs:847-864
+        const int db = (b & 1u) ? -c_mags[sf][b >> 1] : c_mags[sf][b >> 1];
+        s_deq2[sf][t & 63u] = ((unsigned)da & 0xffffu) | ((unsigned)db << 16);
+    }
     if (threadIdx.x < 16) s_grow[threadIdx.x] = 20 * ((c_mags[threadIdx.x][3] + 15) >> 4);
     init_mag_table(s_mags); // (ends with the block barrier)
 
@@ -542,7 +548,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
     uint2 unit_raw[HR]; // the unit's slices of this chain, read back from the stage at the unit top
     (void)unit_raw;
-    const unsigned tab_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_deq[0][0];
+    const unsigned tab_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_deq2[0][0];
     const unsigned grow_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&s_grow[0];
     const unsigned img_lds = (unsigned)(size_t)(lds_ptr)img + my_img;
     int slack = dec_slack(pk);

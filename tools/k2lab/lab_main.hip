@@ -92,7 +92,11 @@ int main(int argc, char **argv) {
     float best = 1e9, sum = 0;
     for (int i = 0; i < runs + 1; i++) {
         (void)hipEventRecord(e0, 0);
+#ifdef LAB_UNIFORM
+        CK(qoa::launch_decode_uniform(nch, enc, pcm, dtab, (unsigned)tab.size(), mm, 0));
+#else
         CK(qoa::launch_decode_frames(nch, true, enc, pcm, dtab, (unsigned)tab.size(), mm, scratch, 0));
+#endif
         (void)hipEventRecord(e1, 0); CK(hipDeviceSynchronize());
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (i) { sum += ms; if (ms < best) best = ms; }
