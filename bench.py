@@ -101,6 +101,8 @@ def launch_ranks(n: int) -> int:
     per GPU) and wait.  This process makes no GPU call before or after (torch.cuda.device_count() does not initialise
     the device).  Rank 0's JSON line goes straight to our stdout; any failing rank ends the others and fails the run."""
     have = torch.cuda.device_count()
+    if os.environ.get("QOA_BENCH_SHARE_GPU") == "1":  # control-flow smoke test on a 1-GPU box (with QOA_DIST_BACKEND=gloo)
+        have = n
     if have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -154,6 +156,8 @@ def main():
 
     rank, world, local_rank = qdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("QOA_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

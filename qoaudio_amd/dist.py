@@ -31,7 +31,9 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # QOA_DIST_BACKEND=gloo: smoke-test the N > 1 control flow on a 1-GPU box (RCCL refuses two ranks on one
+            # device; gloo gathers are staged through host memory below).  Never set in a measured run.
+            backend = os.environ.get("QOA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -39,6 +41,13 @@ def init_from_env(backend: Optional[str] = None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+class _DoneWork:
+    """Stand-in for a finished collective (the host-staged gloo debug path is synchronous)."""
+
+    def wait(self):
+        return True
 
 
 def gather_encoded_async(local: torch.Tensor, n_total: int, dst: int = 0, group=None,
@@ -51,6 +60,16 @@ def gather_encoded_async(local: torch.Tensor, n_total: int, dst: int = 0, group=
     counts = [shard_range(n_total, r, world) for r in range(world)]
     assert all(b - a == local.shape[0] for a, b in counts), "gather_encoded_async needs an even partition"
     send = local if local.is_contiguous() else local.contiguous()
+    if send.is_cuda and dist.get_backend(group) == "gloo":  # debug path only (see init_from_env): host-staged, synchronous
+        host = send.cpu()
+        parts = [torch.empty_like(host) for _ in counts] if rank == dst else None
+        dist.gather(host, gather_list=parts, dst=dst, group=group)
+        if rank == dst:
+            if out is None:
+                out = torch.empty((n_total, local.shape[1]), dtype=local.dtype, device=local.device)
+            for (a, b), p in zip(counts, parts):
+                out[a:b].copy_(p)
+        return _DoneWork(), (out if rank == dst else None)
     if rank != dst:
         return dist.gather(send, gather_list=None, dst=dst, group=group, async_op=True), None
     if out is None:
@@ -97,6 +116,8 @@ def barrier_max_ms(elapsed_ms: float, device) -> float:
     """MAX over ranks of a per-rank elapsed time (bench.py's timing rule)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return elapsed_ms
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([elapsed_ms], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -31,3 +31,25 @@ def test_two_rank_shard_encode_and_rccl_gather(gpu, oracle):
     assert line["gathered_shards_bit_exact_vs_oracle"] is True
     assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)
     assert line["config"]["samples_per_step"] == 2 * 64 * 8 * 5120 * 2
+
+
+def test_two_rank_control_flow_on_one_gpu(gpu, oracle):
+    """The same `python bench.py --gpus 2` on a ONE-GPU box: both ranks share device 0 and the gather is staged through
+    host memory over gloo (QOA_BENCH_SHARE_GPU=1 QOA_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  Not a
+    measurement -- it keeps the launcher, the double-buffered gather loop, the max-over-ranks timing and the gathered-shard
+    check of the N > 1 path exercised where no second GPU exists."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QOA_BENCH_SHARE_GPU="1", QOA_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--clips", "64", "--frames", "8", "--no-cpu"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
+    assert line["bit_exact_vs_oracle"] is True and line["gathered_shards_bit_exact_vs_oracle"] is True
+    assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)
+    assert line["config"]["samples_per_step"] == 2 * 64 * 8 * 5120 * 2
+    assert line["decode"]["header_mismatches"] == 0

@@ -70,6 +70,23 @@ KERNEL(k_med3_ind, "v_med3_i32 %0, %0, %1, %5\n v_med3_i32 %2, %2, %1, %5\n v_me
 KERNEL(k_snop1, "s_nop 1\n")
 KERNEL(k_mov_ind, "v_mov_b32 %0, %1\n v_mov_b32 %2, %1\n v_mov_b32 %3, %1\n v_mov_b32 %4, %1\n")
 
+
+// run lengths of the two issue classes: does a second wavefront's simple ALU op dual-issue only inside long runs?
+KERNEL(k_run_2_2, "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n" "v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_run_4_4, "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_run_8_8, "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_run_16_16, "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_run_12_4, "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1\n" "v_mad_i32_i24 %0, %0, %1, %5\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_run_3_1, "v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_run_1_3, "v_add_u32 %0, %0, %1\n v_mad_i32_i24 %2, %2, %1, %5\n v_mad_i32_i24 %3, %3, %1, %5\n v_mad_i32_i24 %4, %4, %1, %5\n")
+KERNEL(k_maxmin, "v_max_i32 %0, %0, %1\n v_min_i32 %2, %2, %1\n v_max_i32 %3, %3, %1\n v_min_i32 %4, %4, %1\n")
+KERNEL(k_sub_and, "v_sub_u32 %0, %0, %1\n v_and_b32 %2, %2, %1\n v_lshlrev_b32 %3, 1, %3\n v_or_b32 %4, %4, %1\n")
+KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %1, 16\n v_alignbit_b32 %2, %2, %1, 16\n v_alignbit_b32 %3, %3, %1, 16\n v_alignbit_b32 %4, %4, %1, 16\n")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1\n v_lshl_add_u32 %2, %2, 3, %1\n v_lshl_add_u32 %3, %3, 3, %1\n v_lshl_add_u32 %4, %4, 3, %1\n")
+KERNEL(k_sdwa_add, "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_add_u32_sdwa %2, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_add_u32_sdwa %3, %3, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_add_u32_sdwa %4, %4, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n")
+KERNEL(k_pk_ashr, "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %2, 15, %2 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %3, 15, %3 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %4, 15, %4 op_sel_hi:[0,1]\n")
+KERNEL(k_bfe_u, "v_bfe_u32 %0, %0, 3, 6\n v_bfe_u32 %2, %2, 3, 6\n v_bfe_u32 %3, %3, 3, 6\n v_bfe_u32 %4, %4, 3, 6\n")
+
 struct T { const char *name; void (*k)(unsigned long long *, int *, int); int per_body; };
 
 int main() {
@@ -90,6 +107,11 @@ int main() {
         {"v_add_u32_e64 4-indep", k_add_e64_ind, 4}, {"v_or_b32 literal 4-indep", k_or_lit_ind, 4}, {"add/mad24 alternating", k_mix_23, 4},
         {"v_dot2c (VOP2) 4-indep", k_dot2c_ind, 4}, {"2 add + dpp (hazard filled)", k_dpp_filled, 3}, {"v_med3 4-indep", k_med3_ind, 4},
         {"s_nop 1", k_snop1, 1}, {"v_mov_b32 4-indep", k_mov_ind, 4},
+        {"run 2 add + 2 mad24", k_run_2_2, 4}, {"run 4 add + 4 mad24", k_run_4_4, 8}, {"run 8 add + 8 mad24", k_run_8_8, 16},
+        {"run 16 add + 16 mad24", k_run_16_16, 32}, {"run 12 add + 4 mad24", k_run_12_4, 16}, {"3 add + 1 mad24", k_run_3_1, 4}, {"1 add + 3 mad24", k_run_1_3, 4},
+        {"v_max/min_i32 4-indep", k_maxmin, 4}, {"sub/and/lshl/or 4-indep", k_sub_and, 4}, {"v_alignbit 4-indep", k_alignbit, 4},
+        {"v_lshl_add_u32 4-indep", k_lshl_add, 4}, {"v_add_u32_sdwa 4-indep", k_sdwa_add, 4}, {"v_pk_ashrrev_i16 4-indep", k_pk_ashr, 4},
+        {"v_bfe_u32 4-indep", k_bfe_u, 4},
         {"v_sad_u32 dep", k_sad, 1}, {"v_xad_u32 dep", k_xad, 1}, {"v_mul_hi_i32_i24 dep", k_mul_u24_hi, 1},
     };
     printf("%-28s %12s %12s %12s   (cycles per instruction, s_memtime ticks)\n", "test", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
