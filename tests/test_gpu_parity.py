@@ -780,3 +780,45 @@ def test_host_decode_pipeline_and_persistent_handle(gpu, oracle, pinned):
     assert e.value.kind == "InvalidFrameHeader"
     pipe.decode(ro, rclips, rb, chunk_frames=5)  # the handle is still good
     assert np.array_equal(rb.numpy()[:parts[0].size], oracle.decode_all(host_enc[:rclips[1][1]].tobytes())[2])
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_k2u_hostile_full_frames(gpu, oracle, channels):
+    """K2u (the fast path for full 256-row frames of 1 / 2 channels) on streams no encoder writes: random LMS headers and
+    random slices (weights race out of i16 and back), frames that start from extreme header weights and push them further
+    with all-ones slices, quiet music in between -- enough full frames for several wavefronts of the fast path plus a rest
+    that takes the general kernel.  Every stream must equal the oracle's decoder sample for sample: the generated row's
+    slack guard may only ever decline a row, never mis-prove one."""
+    from qoaudio_amd import batch
+    r = np.random.default_rng(2024 + channels)
+    fs = 8 + 16 * channels + 8 * 256 * channels
+    music = oracle.encode_all(rng_pcm(9, 21 * 5120 * channels), channels, 44100, 21 * 5120)
+    hostile = bytearray(_crafted_stream(r, [(channels, 44100, 5120, 256)] * 12, samples_field=12 * 5120))
+    for f in range(12):
+        base = 8 + f * fs
+        hostile[base + 8:base + 8 + 16 * channels] = bytes([0x80, 0x00, 0x7f, 0xff] * (4 * channels))
+        body = base + 8 + 16 * channels
+        n_ff = (10 + 3 * f) * 8 * channels                       # 10..43 rows of sf 15 / code 7: weights leave i16
+        hostile[body:body + n_ff] = b"\xff" * n_ff
+        quiet = body + n_ff + (f % 3) * 40 * 8 * channels          # then stretches of sf 0 / code 0 where they stay put
+        hostile[quiet:base + fs] = bytes(base + fs - quiet)
+    garbage = _crafted_stream(r, [(channels, 8000, 5120, 256)] * 80, samples_field=80 * 5120)
+    streams = [music, bytes(hostile), garbage, music]
+    offs_in, offs_out, a, b = [], [], 0, 0
+    for st, frames in zip(streams, (21, 12, 80, 21)):
+        offs_in.append(a)
+        offs_out.append(b)
+        a += (len(st) + 7) // 8 * 8
+        b += frames * 5120 * channels
+    plan = batch.DecodePlan.from_streams(streams, offs_in, offs_out)
+    assert plan.status == [0, 0, 0, 0]
+    buf = np.zeros(a, np.uint8)
+    for st, o in zip(streams, offs_in):
+        buf[o:o + len(st)] = np.frombuffer(st, np.uint8)
+    out = torch.zeros(b, dtype=torch.int16, device="cuda")
+    plan.run(torch.from_numpy(buf).cuda(), out)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    for st, o, n in zip(streams, offs_out, plan.samples_out):
+        _, _, want = oracle.decode_all(st)
+        assert n == len(want) and np.array_equal(host[o:o + n], want)
