@@ -822,3 +822,25 @@ def test_k2u_hostile_full_frames(gpu, oracle, channels):
     for st, o, n in zip(streams, offs_out, plan.samples_out):
         _, _, want = oracle.decode_all(st)
         assert n == len(want) and np.array_equal(host[o:o + n], want)
+
+
+def test_decode_plan_with_a_pcm_pointer_off_the_16_byte_grid(gpu, oracle):
+    """K2u stores 16-byte pieces at frame offsets that are multiples of 16; a caller may hand the plan a PCM sub-buffer whose
+    base is not.  The plan then sends its uniform-frame table through the general kernel: same samples either way."""
+    from qoaudio_amd import batch
+    n, samples, ch = 40, 2 * 5120, 2   # 80 full stereo frames: two wavefronts of the fast path + a rest
+    desc = gpu.QoaDesc(ch, 44100, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n, desc)
+    pcm = np.stack([rng_pcm(3000 + i, samples * ch) for i in range(n)])
+    enc = np.stack([np.frombuffer(oracle.encode_all(pcm[i], ch, 44100, samples), np.uint8) for i in range(n)])
+    d_enc = torch.from_numpy(enc).cuda()
+    plan = batch.DecodePlan.from_clips(clips)
+    big = torch.zeros(n * per_pcm + 8, dtype=torch.int16, device="cuda")
+    want = np.concatenate([oracle.decode_all(enc[i].tobytes())[2] for i in (0, 17, 39)])
+    for shift in (0, 1, 3, 8):          # element offsets: 0 and 8 keep 16-byte alignment, 1 and 3 do not
+        view = big[shift:shift + n * per_pcm]
+        view.zero_()
+        plan.run(d_enc, view)
+        assert plan.mismatches() == 0
+        host = view.cpu().numpy().reshape(n, -1)
+        assert np.array_equal(np.concatenate([host[i] for i in (0, 17, 39)]), want), shift
