@@ -425,11 +425,14 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 //    (tests/test_k2_disasm.py checks that nothing else touches them) -- parks them in an LDS stage at the unit top and
 //    every lane reads its own 8-byte slices back from there.  vmcnt waits are exact and static: behind a unit's loads
 //    there are only the stores of the unit before (K2uCfg::unit_stores).
-//  * The row as ONE generated asm statement (qoa_decode_asm.inc, tools/gen_decode_asm.py): 10 VALU per sample + 2 for
-//    the table lookup; hipcc's version of the same row spends 14.4.  Its range guard (see the generator) keeps a
-//    running lower bound of 32767 - max|w| instead of recomputing it every row; a row it cannot prove exact executes
-//    nothing and reports flag = 1, the caller then checks exactly and either re-enters or takes the 32-bit step.
-// LDS per wave: 8.3 KB ring + 2.3 KB stage (stereo) -> 12 waves per CU in 4-wave blocks; 16.6 + 2.6 KB (mono) -> 8.
+//  * The row as ONE generated asm statement (qoa_decode_asm.inc, tools/gen_decode_asm.py): 10 VALU per sample + 1.5 for
+//    the lookups in a PAIR table (two codes per LDS read, both weight steps from one packed shift); hipcc's version of
+//    the same row spends 14.4.  Its range guard (see the generator) keeps a running lower bound of 32767 - max|w|
+//    instead of recomputing it every row; a row it cannot prove exact executes nothing and reports flag = 1, the caller
+//    then checks exactly and either re-enters or takes the 32-bit step (rolled loop, cold).
+// LDS: 8.3 KB ring + 2.3 KB stage per wave (stereo), 16.6 + 2.6 KB (mono), + 4.8 KB of tables per block
+// -> 4-wave blocks, 12 (stereo) / 8 (mono) waves per CU.  (K2uCfg is written for 1, 2, 4 and 8 channels; rows are generated
+// for 1 and 2 only -- the general kernel already reaches 0.52-0.54 of peak at 4..8 channels, whose pieces are whole lines.)
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
 struct K2uCfg {
