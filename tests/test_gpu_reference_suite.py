@@ -141,6 +141,37 @@ def test_wav_cli_round_trip(gpu, oracle, tmp_path):
     assert cli.main(["decode", src, dst]) == 1  # a WAV is not a QOA file
 
 
+def test_wav_cli_directory_batches(gpu, oracle, tmp_path):
+    """encode-dir / decode-dir: a directory of WAV files of different shapes as ONE batch through the host pipeline; every
+    .qoa equals the oracle's encode_all of its WAV, every decoded WAV the oracle's decode."""
+    import wave
+    from qoaudio_amd import cli
+    from conftest import rng_pcm
+    wavs, qoas, back = tmp_path / "wav", tmp_path / "qoa", tmp_path / "back"
+    wavs.mkdir()
+    shapes = {"a": (2, 44100, 5120 * 3 + 77), "b": (1, 8000, 333), "c": (2, 44100, 5120 * 40), "d": (6, 48000, 5120 + 1),
+              "e": (1, 22050, 5120 * 70)}
+    pcm = {}
+    for name, (ch, rate, n) in shapes.items():
+        pcm[name] = rng_pcm(len(name) + n, n * ch)
+        with wave.open(str(wavs / f"{name}.wav"), "wb") as w:
+            w.setnchannels(ch)
+            w.setsampwidth(2)
+            w.setframerate(rate)
+            w.writeframes(pcm[name].astype("<i2").tobytes())
+    assert cli.main(["encode-dir", str(wavs), str(qoas)]) == 0
+    for name, (ch, rate, n) in shapes.items():
+        assert (qoas / f"{name}.qoa").read_bytes() == oracle.encode_all(pcm[name], ch, rate, n), name
+    assert cli.main(["decode-dir", str(qoas), str(back)]) == 0
+    for name, (ch, rate, n) in shapes.items():
+        with wave.open(str(back / f"{name}.wav"), "rb") as w:
+            assert (w.getnchannels(), w.getframerate(), w.getnframes()) == (ch, rate, n)
+            got = np.frombuffer(w.readframes(n), dtype="<i2")
+        assert np.array_equal(got, oracle.decode_all((qoas / f"{name}.qoa").read_bytes())[2]), name
+    (qoas / "broken.qoa").write_bytes((qoas / "a.qoa").read_bytes()[:-8])     # size disagrees with its header
+    assert cli.main(["decode-dir", str(qoas), str(back)]) == 2
+
+
 def test_c_example_round_trip(gpu, tmp_path):
     """examples/roundtrip.c: the C ABI from plain C, encode_all + decode_all on host buffers."""
     import subprocess
