@@ -59,16 +59,18 @@ def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
         return None, "traffic_stale: kernel sources changed since the PMC profile " + str(d.get("source"))
     return d[kernel]["traffic_bytes_per_launch"], None
 
-def valu_issue(n_chains: int, samples: int, kernel_ms: float):
+def valu_issue(n_chains: int, samples: int, kernel_ms: float, per_slice: float = 660.0):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
-    Instruction count per slice is the PMC-measured 660 (SQ_INSTS_VALU / slices / waves, config 3, CPW = 4,
-    profiles/r01i_pmc_summary.txt); a lone wavefront per SIMD can issue at most one instruction per 4 cycles."""
+    Instruction count per slice is PMC-measured (SQ_INSTS_VALU / slices / waves): 660 for the register-table step form
+    (config 3, profiles/r02_pmc_summary.txt), 501 (+ 29 LDS) for the LDS-table form that launches with >= 2 wavefronts per
+    SIMD use (profiles/r02_pmc_summary.txt, full-chip note); a SIMD issues at most one instruction per 4 cycles whatever
+    the wavefront count (profiles/r02_ubench_gfx950_issue_classes.txt)."""
     waves = (n_chains + 3) // 4
     slices = (samples + 19) // 20
-    achieved = 660.0 * slices * waves / (kernel_ms * 1e-3)
+    achieved = per_slice * slices * waves / (kernel_ms * 1e-3)
     peak = 1024 * 2.4e9 / 4.0
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s",
-            "frac": achieved / peak, "wavefronts": waves}
+            "frac": achieved / peak, "wavefronts": waves, "valu_per_slice": per_slice}
 
 
 def cpu_baseline_child(pcm_host: np.ndarray, rate: int, budget_s: float):
@@ -336,7 +338,10 @@ def main():
                                                                           args.rate, fc_samples)
         extras["full_chip"] = {"workload": f"{fc_clips} clips x {ch} ch x {fc_frames} frames (4 wavefronts per SIMD)",
                                "kernel_ms_avg": f_ms, "samples_per_s": fplan.samples / (f_ms * 1e-3),
-                               "valu_issue": valu_issue(fc_clips * ch, fc_samples, f_ms), "bit_exact_vs_oracle": bool(f_ok)}
+                               "step_form": "LDS-table (501 VALU + 29 LDS per slice)" if fc_clips * ch // 4 >= 2048
+                               else "register-table (660 VALU per slice)",
+                               "valu_issue": valu_issue(fc_clips * ch, fc_samples, f_ms, 501.0 if fc_clips * ch // 4 >= 2048 else 660.0),
+                               "bit_exact_vs_oracle": bool(f_ok)}
         result["k1_extras"] = extras
         del fplan, fout
         torch.cuda.synchronize()

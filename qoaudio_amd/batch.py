@@ -17,6 +17,8 @@ PLAN_DEFAULT = 0
 PLAN_FORCE_GENERIC_PATH = 1
 PLAN_FORCE_32BIT_STEP = 2
 PLAN_NO_SPECULATION = 4
+PLAN_LDS_TABLES = 8
+PLAN_NO_LDS_TABLES = 128
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 
 

@@ -225,14 +225,20 @@ extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_
 }
 
 // kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
-// bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps
+// bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) |
                       ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u);
     for (auto *g : plan->groups) {
+        // The LDS-table step form spends fewer issue slots per slice but one LDS round trip per step: it pays once a launch
+        // gives every SIMD several wavefronts to cover that latency (>= 2 per SIMD on the 1024 SIMDs of the chip); below that
+        // the serial chain of a lone wavefront would wait for the table 20 times per slice.
+        unsigned lds = 0;
+        if (plan->flags & QOA_PLAN_LDS_TABLES) lds = 16u;
+        else if (!(plan->flags & QOA_PLAN_NO_LDS_TABLES) && (g->n + g->cpw - 1) / g->cpw >= 2048u) lds = 16u;
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
-                              kflags, (unsigned long long *)plan->stats.p, (hipStream_t)stream),
+                              kflags | lds, (unsigned long long *)plan->stats.p, (hipStream_t)stream),
                 QOA_ENCODE_IO_ERROR);
     }
     return QOA_OK;

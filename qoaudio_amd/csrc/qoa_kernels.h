@@ -10,6 +10,8 @@ namespace qoa {
 // flags bit0: run every slice through the rolled tail path (debug / parity tests)
 //       bit1: start every chain from a fresh encoder's LMS state instead of loading d_lms
 //       bit2: never take the i16-packed fast path      bit3: no speculative (penalty-free) steps
+//       bit4: speculative steps with the quantiser / dequantiser in an LDS table (fewer issue slots, one LDS round trip per
+//             step: for launches with several wavefronts per SIMD)
 // d_stats (may be null, 3 x u64): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
 //                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible,
 //                        [2] += (chain, slice) pairs whose speculative evaluation was repeated by the full form

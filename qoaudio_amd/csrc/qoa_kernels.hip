@@ -317,6 +317,34 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
     return done;
 }
 
+// run_block_spec with the quantiser / dequantiser in an LDS table (QOA_BLOCK_SPEC_LDSQ_ASM_TEXT, tools/gen_slice_asm.py:
+// pk_step_ldsq): 22 VALU + 1 LDS read per step instead of 30 VALU.  `qtab` = LDS byte address of this lane's table entry for
+// scaled = 0 (entries for scaled = -8..8 sit at qtab - 32 .. qtab + 32).  Used when the launch gives every SIMD several
+// wavefronts, which hide the read's latency; a lone wavefront would wait for it 20 times per slice.
+__device__ __forceinline__ unsigned run_block_spec_ldsq(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
+                                                        int sf, const StepConst &k, int limq, int winq, unsigned qtab, unsigned n,
+                                                        PkLms &pk) {
+    register unsigned w01 asm("v84") = pk.w01;
+    register unsigned w23 asm("v85") = pk.w23;
+    register unsigned pa asm("v86") = pk.pa;
+    register unsigned pb asm("v87") = pk.pb;
+    unsigned done;
+    asm volatile(QOA_BLOCK_SPEC_LDSQ_ASM_TEXT
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
+                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [qtab] "v"(qtab),
+                   [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
+                   [rnd] "s"(1 << 15), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),
+                   [mf0] "s"(0xf0), [pp] "s"(pp)
+                 : "vcc", "scc", "memory", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                   "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+                   "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                   "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+                   "v124", "v125", "v126", "v127");
+    pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
+    return done;
+}
+
 // Thresholds of the speculative form for scalefactor sf, in units of (weight energy - (0x8ff << 18)) as the steps sample
 // it.  One step changes the energy S = sum w^2 by at most 2 d sum|w| + 4 d^2 <= 4 d sqrt(S) + 4 d^2 with
 // d = ceil(mag3(sf) / 16) the largest weight step (sum|w| <= 2 sqrt(S)).  Three steps go unsampled after each sample:
@@ -434,6 +462,19 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // [0,16): the block's winning slices, [16,32): per-lane dummies; 48 entries = 384 B per chain so that the two
     // chains a 64-lane ds_write_b64 serves per pass fall on disjoint banks
     __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][48];
+    // quantiser + dequantiser table of the LDS-table step form (flags bit 4): [sf][scaled + 8] = dequant & 0xffff | code << 29
+    // with code = QOA_QUANT_TAB[scaled + 8] (src/lib.rs:22), dequant = QOA_DEQUANT_TAB[sf][code] (:847-864)
+    __shared__ unsigned s_qtab[16][17];
+    if (flags & 16u) {
+        for (unsigned t = threadIdx.x; t < 16 * 17; t += blockDim.x) {
+            const unsigned tsf = t / 17, idx = t % 17;
+            const int c = (int)idx - 8, ac = c < 0 ? -c : c;
+            const unsigned level = (unsigned)(ac > 7 ? 7 : ac) >> 1, code = 2 * level + (c < 0 ? 1u : 0u);
+            const int deq = c < 0 ? -c_mags[tsf][level] : c_mags[tsf][level];
+            s_qtab[tsf][idx] = ((unsigned)deq & 0xffffu) | (code << 29);
+        }
+        __syncthreads();
+    }
     const unsigned lane = threadIdx.x & 63u;
     const unsigned grp = lane >> 4;
     if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle
@@ -464,6 +505,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const bool force_tail_path = (flags & 1u) != 0;
     const bool allow_packed = (flags & 4u) == 0; // bit 2: 32-bit step only (tests compare the two)
     const bool allow_spec = (flags & 8u) == 0;   // bit 3: no speculative (penalty-free) steps
+    const bool lds_tables = (flags & 16u) != 0;  // bit 4: speculative steps look the quantiser up in LDS (full-chip launches)
+    const unsigned qtab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_qtab[sf][8];
     int limq, winq;
     spec_limits(sf, limq, winq);
     unsigned spec_cooldown = 0; // blocks left on the full form after a speculation miss (wave-uniform)
@@ -535,7 +578,11 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 typedef __attribute__((address_space(3))) int *lds_int;
                 const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
                 if (allow_spec && spec_cooldown == 0) {
-                    j = run_block_spec(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk);
+                    j = lds_tables ? run_block_spec_ldsq(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq,
+                                                         qtab_addr, kBlockSlices, pk)
+                                   : run_block_spec(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq,
+                                                    kBlockSlices, pk);
+                    j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: both forms return an SGPR)
                     if (j < kBlockSlices) { // slice j could not be proven: the full form takes over, here and for a while
                         spec_cooldown = kSpecCooldownBlocks + 1;
                         if (stats && sf == 0) atomicAdd(&stats[2], 1ull);

@@ -129,14 +129,15 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "nospec"])
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "nospec", "ldsq", "ldsq_cpw1"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
     fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
           "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP,
-          "nospec": batch.PLAN_NO_SPECULATION}[flags]
+          "nospec": batch.PLAN_NO_SPECULATION, "ldsq": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_4,
+          "ldsq_cpw1": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_1}[flags]
     shapes = [(2, 5300), (1, 41), (2, 20), (3, 999), (2, 12000), (1, 6000), (8, 333), (2, 1), (1, 5120), (2, 5121),
               (5, 777), (2, 640), (1, 10240), (2, 319)]
     clips, pcm_parts, pcm_off, out_off = [], [], 0, 0

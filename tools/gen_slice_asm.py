@@ -170,6 +170,64 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     return L
 
 
+def pk_step_ldsq(i, N):
+    """Speculative step with the quantiser in an LDS table (BASELINE.json's "tables staged in LDS"): for batches that give
+    every SIMD several wavefronts, where the ~100 cycles of the lookup are covered by the other wavefronts and what counts
+    is the issue-slot total.  scaled -> clamp(-8, 8) -> entry [sf][c + 8] = dequant & 0xffff | code << 29 replaces the
+    closed-form quantiser + v_perm dequant + sign fix-ups of pk_step(): 22 (25 at a sampling step) VALU + 1 LDS read
+    instead of 30 (33).  Same values: QOA_QUANT_TAB / QOA_DEQUANT_TAB (src/lib.rs:22, :847-864) are what the closed form
+    was derived from.  The order below keeps the v_dot2 / v_pk wait states by construction (not list-scheduled: the
+    read's wait is a fence, and with other wavefronts filling the slots dependent issue costs nothing)."""
+    R, S, RC = N["R"], PK_S, PK_RC
+    A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
+    SA, SB = S[(i + 2) % 4], S[i % 4]
+    smp = f"v{SMP0 + i}"
+    acc = N["acca"] if i < 10 else N["accb"]
+    w01, w23, e = N["w01"], N["w23"], N["e"]
+    rc = RC[i % 2]
+    P, Q, PR, T, U, SN, D, X, E = (f"v{r}" for r in (PK_P, PK_Q, PK_PR, PK_T, PK_U, PK_SN, PK_D, PK_X, PK_E))
+    if i == 0:
+        slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"
+    else:
+        slot_a = f"v_sub_u32 {E}, v{SMP0 + i - 1}, {RC[(i - 1) % 2]}"      # err of the previous step
+        slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}"
+    check = i % 4 == 0
+    L = [
+        f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
+        f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]" if check else None,     # sum w^2 - (0x8ff << 18), sampled
+        f"v_dot2_i32_i16 {P}, {w23}, {B}, {P}",
+        f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}" if check else None,
+        f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",
+        slot_a,
+        f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",
+        f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
+        f"v_sub_u32 {T}, {smp}, {PR}",                      # residual
+        slot_b,
+        f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
+        f"v_med3_i32 {T}, {T}, -1, 1",
+        (f"v_mov_b32 {N['qm']}, {Q}" if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
+        f"v_ashrrev_i32 {U}, 16, {U}",
+        f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
+        f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled (qoa_div, src/lib.rs:613-617)
+        f"v_med3_i32 {U}, {U}, -8, 8",                      # :569
+        f"v_lshl_add_u32 {X}, {U}, 2, %[qtab]",
+        f"ds_read_b32 {X}, {X}",
+        "s_waitcnt lgkmcnt(0)",
+        f"v_alignbit_b32 {acc}, {acc}, {X}, 29",            # slice = slice << 3 | code (:584)
+        f"v_add_u32_sdwa {U}, {PR}, sext({X}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0",
+        f"v_bfe_i32 {D}, {X}, 4, 12",                       # delta = dequantised >> 4 (:822)
+        f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
+        f"v_pk_mad_i16 {w01}, {SA}, {D}, {w01} op_sel_hi:[1,0,1]",
+        f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
+        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
+    ]
+    L = [l for l in L if l is not None]
+    if i == 1:  # |err| of the first sample, right after slot_a produced it
+        k = L.index(slot_a) + 1
+        L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
+    return L
+
+
 def pk_zero(N):
     return [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0"]
 
@@ -298,7 +356,7 @@ def schedule(lines):
     return order, back_to_back
 
 
-def pk_block(verbose=False, spec=False):
+def pk_block(verbose=False, spec=False, ldsq=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -340,14 +398,19 @@ def pk_block(verbose=False, spec=False):
         "s_waitcnt lgkmcnt(1)",                              # the winner's state (only a slice-word store may trail)
     ]
     body = pk_prologue(N, zero=False)                        # rank and penalty sums are cleared in the election's gaps
+    if ldsq:
+        N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
     for i in range(20):
-        body += pk_step(i, N, spec)
-    E = N["alt"][8]                                          # step 19 used the second temporary set
+        body += pk_step_ldsq(i, N) if ldsq else pk_step(i, N, spec)
+    E = f"v{PK_E}" if ldsq else N["alt"][8]                  # step 19 used the second temporary set
     body += [
         f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
         f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
     ] + ([] if spec else [f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}"])   # total rank = sum err^2 + sum penalty^2
-    body, b2b = schedule(body)
+    if ldsq:
+        b2b = -1                                             # kept in program order (see pk_step_ldsq)
+    else:
+        body, b2b = schedule(body)
     if verbose:
         print(f"block body{' (speculative)' if spec else ''}: {len(body)} instructions after scheduling, "
               f"{b2b} consumers directly behind their producer")
@@ -422,6 +485,7 @@ def render(verbose=False):
     pk = pk_slice()
     blk = pk_block(verbose)
     blk_spec = pk_block(verbose, spec=True)
+    blk_ldsq = pk_block(verbose, spec=True, ldsq=True)
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
@@ -430,8 +494,11 @@ def render(verbose=False):
            "// QOA_BLOCK_SPEC_ASM_TEXT: the same loop with speculative steps (30/33 instructions, no penalty arithmetic) and\n"
            "//   the two energy tests that prove a slice's result; fixed registers v64-v127.\n"
            + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk) + "\n"
-           + emit("QOA_BLOCK_PK_ASM_TEXT", blk) + "\n" + emit("QOA_BLOCK_SPEC_ASM_TEXT", blk_spec))
-    return out, (len(lines), len(pk), len(blk), len(blk_spec))
+           + emit("QOA_BLOCK_PK_ASM_TEXT", blk) + "\n" + emit("QOA_BLOCK_SPEC_ASM_TEXT", blk_spec) + "\n"
+           + "// QOA_BLOCK_SPEC_LDSQ_ASM_TEXT: the speculative loop with the quantiser + dequantiser in an LDS table (22/25\n"
+           + "//   VALU + 1 LDS read per step): for launches that give every SIMD several wavefronts.\n"
+           + emit("QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", blk_ldsq))
+    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq))
 
 
 INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
@@ -441,7 +508,7 @@ def main():
     out, counts = render(verbose=True)
     with open(INC_PATH, "w") as f:
         f.write(out)
-    print(f"wrote {INC_PATH}: {counts[0]} + {counts[1]} + {counts[2]} + {counts[3]} lines")
+    print(f"wrote {INC_PATH}: " + " + ".join(str(c) for c in counts) + " lines")
 
 
 if __name__ == "__main__":
