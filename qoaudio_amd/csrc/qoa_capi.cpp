@@ -288,6 +288,17 @@ struct qoa_host_pipeline {
 };
 typedef qoa_host_pipeline HostPipe;
 
+// Whatever path a pipeline call leaves by (an error in the middle included), no copy into or out of the caller's host
+// buffers may still be in flight when it returns: the caller is free to release them.
+struct PipeDrain {
+    HostPipe &p;
+    ~PipeDrain() {
+        if (p.s_in) (void)hipStreamSynchronize(p.s_in);
+        if (p.s_k) (void)hipStreamSynchronize(p.s_k);
+        if (p.s_out) (void)hipStreamSynchronize(p.s_out);
+    }
+};
+
 static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
                             uint32_t chunk_frames) {
     if (!clips || !h_pcm || !h_out) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
@@ -322,6 +333,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
               clips[1].out_offset - clips[0].out_offset >= qoa_encoded_size(clips[0].desc.channels, clips[0].desc.samples);
 
     HIP_TRY(P.init(), QOA_ENCODE_IO_ERROR);
+    PipeDrain drain{P};
     size_t n_chains_total = 0;
     for (size_t i = 0; i < n_clips; i++) n_chains_total += clips[i].desc.channels;
     for (int b = 0; b < 2; b++) {
@@ -983,6 +995,7 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
     const uint32_t F = chunk_frames ? chunk_frames : 8;
     const uint32_t n_chunks = (max_frames + F - 1) / F;
     HIP_TRY(P.init(), QOA_DECODE_IO_ERROR);
+    PipeDrain drain{P};
     if (!P.dec) P.dec = new (std::nothrow) DecTablesHolder();
     if (!P.dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
 
