@@ -134,6 +134,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_NO_SPECULATION 4u     /* debug: packed path always with its penalty arithmetic (same bytes) */
 #define QOA_PLAN_LDS_TABLES 8u         /* debug: quantiser / dequantiser looked up in an LDS table in every launch (same bytes; */
 #define QOA_PLAN_NO_LDS_TABLES 128u    /*        default: only in launches with >= 2 wavefronts per SIMD) / in none */
+#define QOA_PLAN_EXACT_QUOTIENT 256u   /* debug: speculative steps always with the exact qoa_div fix-up (same bytes) */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
 #define QOA_PLAN_CPW_2 (2u << 4)
 #define QOA_PLAN_CPW_4 (4u << 4)
@@ -158,6 +159,10 @@ int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_
  * The first two are 0 on ordinary audio.  Any pointer may be null. */
 int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices,
                           uint64_t *speculation_misses);
+/* The same three counters plus out[3] = slices the cheap-quotient step form declined (level from |quotient|, sign from the
+ * residual: exact unless a scalefactor-0/1 candidate's quotient wraps to the opposite sign; such a slice is declined when
+ * the winner cannot be proven against that candidate, and repeated with the exact qoa_div -- loud passages show these). */
+int qoa_encode_plan_stats4(qoa_encode_plan *plan, uint64_t out[4]);
 
 /* ---- batch encode on HOST-resident buffers: time-sliced pipeline ----
  * Semantically encode_all per clip (src/lib.rs:760-763) with h_pcm / h_out in host memory (pinned memory makes

@@ -19,6 +19,7 @@ PLAN_FORCE_32BIT_STEP = 2
 PLAN_NO_SPECULATION = 4
 PLAN_LDS_TABLES = 8
 PLAN_NO_LDS_TABLES = 128
+PLAN_EXACT_QUOTIENT = 256
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 
 
@@ -82,6 +83,14 @@ class EncodePlan:
         if rc:
             raise EncodeError(rc)
         return a.value, b.value, c.value
+
+    def stats4(self) -> Tuple[int, int, int, int]:
+        """stats() plus the slices the cheap-quotient step form declined (qoa_encode_plan_stats4)."""
+        out = (C.c_uint64 * 4)()
+        rc = _lib.lib().qoa_encode_plan_stats4(self._h, out)
+        if rc:
+            raise EncodeError(rc)
+        return tuple(int(v) for v in out)
 
 
 class DecodePlan:

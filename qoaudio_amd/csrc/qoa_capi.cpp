@@ -138,7 +138,7 @@ struct qoa_encode_plan {
     std::vector<EncGroup *> groups;
     uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;
     uint32_t flags = 0;
-    DevBuf stats; // 3 x u64, accumulated over every run of the plan
+    DevBuf stats; // 4 x u64, accumulated over every run of the plan
     ~qoa_encode_plan() { for (auto *g : groups) delete g; }
 };
 
@@ -186,8 +186,8 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
     plan->samples = samples;
     plan->flags = flags;
     {
-        hipError_t e = plan->stats.reserve(3 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemset(plan->stats.p, 0, 3 * sizeof(uint64_t));
+        hipError_t e = plan->stats.reserve(4 * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemset(plan->stats.p, 0, 4 * sizeof(uint64_t));
         if (e != hipSuccess) {
             delete plan;
             return fail_hip(e, "encode plan counters", QOA_ENCODE_IO_ERROR);
@@ -225,11 +225,13 @@ extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_
 }
 
 // kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
-// bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table
+// bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table,
+// bit5 no cheap-quotient speculative steps
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) |
-                      ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u);
+                      ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) |
+                      ((plan->flags & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u);
     for (auto *g : plan->groups) {
         // The LDS-table step form spends fewer issue slots per slice but one LDS round trip per step: it pays once a launch
         // gives every SIMD several wavefronts to cover that latency (>= 2 per SIMD on the 1024 SIMDs of the chip); below that
@@ -253,6 +255,13 @@ extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_s
     if (declined_slices) *declined_slices = h[0];
     if (unpacked_slices) *unpacked_slices = h[1];
     if (speculation_misses) *speculation_misses = h[2];
+    return QOA_OK;
+}
+
+extern "C" int qoa_encode_plan_stats4(qoa_encode_plan *plan, uint64_t out[4]) {
+    if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(out, plan->stats.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
     return QOA_OK;
 }
 

@@ -294,6 +294,13 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
 // one, and the reference's winner is this winner.  Margins for the three unsampled steps are folded into limq / winq
 // (spec_limits).  A slice that fails either test ends the call (done < n) with its entry state restored; the caller runs
 // it through the full form.  `pp` = byte distance between the two candidate-slot buffers.
+//
+// CHEAP selects QOA_BLOCK_CHEAP_ASM_TEXT, the same loop with the cheap quotient (tools/gen_slice_asm.py: cheap_quotient_note):
+// 25 / 28 instructions per step.  The quantiser's level is taken from |n| and its sign from the residual, which is what the
+// reference computes unless the wrapped quotient n and the residual have opposite signs (scalefactors 0 and 1 only); such a
+// candidate is marked, leaves the election, and the winner's rank must stay below the bound that comes with the slice's
+// samples (tile record dword 0: what a marked candidate provably costs) -- else the slice is declined like a speculation miss.
+template <bool CHEAP>
 __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
                                                    int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk) {
     register unsigned w01 asm("v84") = pk.w01;
@@ -301,18 +308,24 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
     register unsigned pa asm("v86") = pk.pa;
     register unsigned pb asm("v87") = pk.pb;
     unsigned done;
-    asm volatile(QOA_BLOCK_SPEC_ASM_TEXT
-                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
-                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
-                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
-                   [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
-                   [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),
-                   [mf0] "s"(0xf0), [pp] "s"(pp)
-                 : "vcc", "scc", "memory", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
-                   "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
-                   "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
-                   "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
-                   "v124", "v125", "v126", "v127");
+#define QOA_SPEC_OPERANDS                                                                                                  \
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)                                             \
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),                           \
+                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), \
+                   [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),          \
+                   [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),        \
+                   [mf0] "s"(0xf0), [pp] "s"(pp)                                                                            \
+                 : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
+                   "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92",    \
+                   "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",    \
+                   "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",     \
+                   "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+    if constexpr (CHEAP) {
+        asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT QOA_SPEC_OPERANDS);
+    } else {
+        asm volatile(QOA_BLOCK_SPEC_ASM_TEXT QOA_SPEC_OPERANDS);
+    }
+#undef QOA_SPEC_OPERANDS
     pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
     return done;
 }
@@ -336,7 +349,7 @@ __device__ __forceinline__ unsigned run_block_spec_ldsq(unsigned tile_addr, unsi
                    [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
                    [rnd] "s"(1 << 15), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),
                    [mf0] "s"(0xf0), [pp] "s"(pp)
-                 : "vcc", "scc", "memory", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                 : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
                    "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
                    "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
                    "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
@@ -430,19 +443,58 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlockSlices = 16;
 constexpr unsigned kSpecCooldownBlocks = 4; // blocks on the full step form after a speculation miss (misses cluster)
-constexpr int kTileInts = kBlockSlices * 20 + 4; // +16 B: the 4 chain tiles of a wave start on different banks
+constexpr unsigned kCheapCooldownBlocks = 2; // blocks on the exact-quotient form after the cheap-quotient form declined a slice
+// A slice's tile record is 12 dwords (three ds_read_b128): [0] marked_bound() of the slice, [1] unused, [2..11] its 20
+// samples as 10 i16 pairs.  One record of slack: the block loops prefetch one slice past their last.  (17 * 12 = 204 dwords:
+// the 4 chain tiles of a wave start 12 banks apart.)
+constexpr int kSliceDwords = 12;
+constexpr int kTileInts = (kBlockSlices + 1) * kSliceDwords;
 
 template <int NCH>
 __device__ __forceinline__ void load_block_lane(const int16_t *__restrict__ p, unsigned slice_idx, unsigned samples,
-                                                int (&v)[20]) {
+                                                unsigned (&v)[10]) {
     // p = this channel's sample 0; sample t is p[t*NCH].  Indices past the clip end are clamped to its
     // last sample: the values are never used (the tail path stops at the slice length).
-    // Branch-free on purpose: an if/else here makes the 20 values a phi of vectors, which hipcc keeps
-    // as a 32-register tuple and guards with vmcnt waits inside the slice loop.
+    // Branch-free on purpose: an if/else here makes the values a phi of vectors, which hipcc keeps
+    // as a register tuple and guards with vmcnt waits inside the slice loop.
+    // v[k] = samples (2k, 2k+1) of the slice as an i16 pair, the earlier one in the low half.
     const unsigned long long base = (unsigned long long)slice_idx * 20u;
     const unsigned long long last = samples - 1u;
 #pragma unroll
-    for (int i = 0; i < 20; i++) v[i] = p[min(base + (unsigned)i, last) * NCH];
+    for (int k = 0; k < 10; k++) {
+        const unsigned lo = (unsigned short)p[min(base + (unsigned)(2 * k), last) * NCH];
+        const unsigned hi = (unsigned short)p[min(base + (unsigned)(2 * k + 1), last) * NCH];
+        v[k] = lo | (hi << 16);
+    }
+}
+
+// What a candidate of the slice costs at least if its quotient wraps to the opposite sign (cheap-quotient form, see
+// run_block_spec): at that step |residual| >= 32768 and |dequantised| <= 49, so |error| >= min(32719, 32767 - max|sample|).
+// Returns the square; the block loop demands that the winner's rank stays below it whenever a candidate was marked.
+__device__ __forceinline__ unsigned marked_bound(const unsigned (&pairs)[10]) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 mx = __builtin_bit_cast(s16x2, pairs[0]), mn = mx;
+#pragma unroll
+    for (int k = 1; k < 10; k++) {
+        const s16x2 v = __builtin_bit_cast(s16x2, pairs[k]);
+        mx = __builtin_elementwise_max(mx, v);
+        mn = __builtin_elementwise_min(mn, v);
+    }
+    const int hi = max((int)mx.x, (int)mx.y), lo = min((int)mn.x, (int)mn.y);
+    const int smax = max(hi, -lo);
+    const int lb = max(min(32719, 32767 - smax), 0);
+    return (unsigned)(lb * lb);
+}
+
+// the slice at `src` (tile layout: bound, unused, 10 pairs) widened to 20 ints
+__device__ __forceinline__ void unpack_tile_slice(const int *src, int (&smp)[20]) {
+    const int4 a = ((const int4 *)src)[0], b = ((const int4 *)src)[1], c = ((const int4 *)src)[2];
+    const int pk[10] = {a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        smp[2 * k] = (int)(short)pk[k];
+        smp[2 * k + 1] = pk[k] >> 16;
+    }
 }
 
 template <int CPW, int NCH>
@@ -450,8 +502,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                                                          const EncChain *__restrict__ chains, unsigned n_chains,
                                                          int32_t *__restrict__ lms_state, unsigned flags,
                                                          unsigned long long *__restrict__ stats) {
-    // sample tiles [wave][chain][kTileInts] + one slice of slack: the block loop prefetches one slice past its last
-    __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts + 20];
+    // sample tiles [wave][chain][kTileInts]
+    __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts];
     // candidate end states of the slice in flight; two buffers: the speculative loop alternates between them so that
     // a slice's entry state (the previous winner's slot) survives until the slice is known to be final.  It switches
     // buffers with one v_xor of the slot address, so the pair must be aligned to its own size (and a row's 16 slots to
@@ -506,10 +558,12 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const bool allow_packed = (flags & 4u) == 0; // bit 2: 32-bit step only (tests compare the two)
     const bool allow_spec = (flags & 8u) == 0;   // bit 3: no speculative (penalty-free) steps
     const bool lds_tables = (flags & 16u) != 0;  // bit 4: speculative steps look the quantiser up in LDS (full-chip launches)
+    const bool allow_cheap = (flags & 32u) == 0; // bit 5: no cheap-quotient steps
     const unsigned qtab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_qtab[sf][8];
     int limq, winq;
     spec_limits(sf, limq, winq);
-    unsigned spec_cooldown = 0; // blocks left on the full form after a speculation miss (wave-uniform)
+    unsigned spec_cooldown = 0;  // blocks left on the full form after a speculation miss (wave-uniform)
+    unsigned cheap_cooldown = 0; // blocks left on the exact-quotient speculative form after the cheap one declined a slice
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -532,16 +586,17 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     }
     constexpr unsigned kFrameBytes = 8 + 16 * NCH + 8 * kSlicesPerFrame * NCH; // a full frame
 
-    int pre[20];                       // lane j: samples of slice 16*(blk+1)+j, in flight during block blk
+    unsigned pre[10];                  // lane j: samples of slice 16*(blk+1)+j (i16 pairs), in flight during block blk
     // the winning slice of row 16*blk+j waits in out_tile[j] (LDS) for the flush at the next block top
     load_block_lane<NCH>(p, (unsigned)sf, samples, pre);
 
     for (unsigned blk = 0; blk < nblocks; blk++) {
         // ---------------- block top: every vector-memory instruction of the loop lives here ----------------
         {
-            int4 *dst = (int4 *)(tile + sf * 20); // needs the prefetched samples: the only vmcnt wait of the loop
-#pragma unroll
-            for (int q = 0; q < 5; q++) dst[q] = make_int4(pre[4 * q], pre[4 * q + 1], pre[4 * q + 2], pre[4 * q + 3]);
+            int *dst = tile + sf * kSliceDwords; // needs the prefetched samples: the only vmcnt wait of the loop
+            ((uint4 *)dst)[0] = make_uint4(marked_bound(pre), 0u, pre[0], pre[1]);
+            ((uint4 *)dst)[1] = make_uint4(pre[2], pre[3], pre[4], pre[5]);
+            ((uint4 *)dst)[2] = make_uint4(pre[6], pre[7], pre[8], pre[9]);
         }
         if (blk > 0) { // flush the previous block's 16 slices (always a full block)
             const unsigned k = (blk - 1) * kBlockSlices + (unsigned)sf;
@@ -578,11 +633,26 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 typedef __attribute__((address_space(3))) int *lds_int;
                 const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
                 if (allow_spec && spec_cooldown == 0) {
-                    j = lds_tables ? run_block_spec_ldsq(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq,
-                                                         qtab_addr, kBlockSlices, pk)
-                                   : run_block_spec(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq,
-                                                    kBlockSlices, pk);
-                    j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: both forms return an SGPR)
+                    if (lds_tables) {
+                        j = run_block_spec_ldsq(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, qtab_addr,
+                                                kBlockSlices, pk);
+                    } else {
+                        if (allow_cheap && cheap_cooldown == 0) {
+                            j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq,
+                                                     kBlockSlices, pk);
+                            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+                            if (j < kBlockSlices) { // loud passage (or a genuine miss): the exact quotient for a while
+                                cheap_cooldown = kCheapCooldownBlocks + 1;
+                                if (stats && sf == 0) atomicAdd(&stats[3], 1ull);
+                            }
+                        }
+                        if (j < kBlockSlices) {
+                            const unsigned j0 = j;
+                            j += run_block_spec<false>(tile0 + 4u * kSliceDwords * j0, cand_addr, kCandBufBytes, outb_addr + 8u * j0,
+                                                       dummy_addr, sf, kc, limq, winq, kBlockSlices - j0, pk);
+                        }
+                    }
+                    j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: all forms return an SGPR)
                     if (j < kBlockSlices) { // slice j could not be proven: the full form takes over, here and for a while
                         spec_cooldown = kSpecCooldownBlocks + 1;
                         if (stats && sf == 0) atomicAdd(&stats[2], 1ull);
@@ -590,18 +660,19 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 }
                 if (j < kBlockSlices) {
                     const unsigned j0 = j;
-                    j += run_block_pk(tile0 + 80u * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
+                    j += run_block_pk(tile0 + 4u * kSliceDwords * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
                     // (a decline found here is counted once, by the slice loop below, which evaluates slice j again)
                 }
             }
             if (spec_cooldown) spec_cooldown--;
+            if (cheap_cooldown) cheap_cooldown--;
         }
         for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);
             const bool full = (len == 20) && !force_tail_path;
 
             typedef __attribute__((address_space(3))) int *lds_ptr;
-            const unsigned tile_addr = (unsigned)(size_t)(lds_ptr)(tile + j * 20);
+            const unsigned tile_addr = (unsigned)(size_t)(lds_ptr)(tile + j * kSliceDwords);
             if (__builtin_amdgcn_ballot_w64(!(full && packed)) == 0ull) { // every chain of the wave can go packed
                 PkResult pr;
                 run_slice_pk(tile_addr, sf, kc, pk, pr);
@@ -629,12 +700,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 run_slice_asm(tile_addr, sf, kc, st, r);
             } else {
                 int smp[20];
-                const int4 *src = (const int4 *)(tile + j * 20); // same address in all 16 lanes: LDS broadcast
-#pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    const int4 v = src[q];
-                    smp[4 * q] = v.x; smp[4 * q + 1] = v.y; smp[4 * q + 2] = v.z; smp[4 * q + 3] = v.w;
-                }
+                unpack_tile_slice(tile + j * kSliceDwords, smp); // same address in all 16 lanes: LDS broadcast
                 run_slice_tail(smp, len, sf, kc, st, r);
             }
             const unsigned win = pick_winner(r.e, r.pen, r.aerr0, sf);
@@ -698,12 +764,12 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
     CandResult r;
     // generic: 0 = one-asm 32-bit slice (samples staged in LDS), 1 = rolled tail path, 2 = 20 cand_step() statements,
     // 3 = packed fast path
-    __shared__ __attribute__((aligned(16))) int s_dbg[20];
+    __shared__ __attribute__((aligned(16))) int s_dbg[kSliceDwords]; // one slice in the tile layout
     bool declined = false;
     if ((generic == 0 || generic == 3 || generic == 4) && len == 20) {
         if (sf == 0) {
 #pragma unroll
-            for (int i = 0; i < 20; i++) s_dbg[i] = smp[i];
+            for (int k = 0; k < 10; k++) s_dbg[2 + k] = (int)(((unsigned)smp[2 * k] & 0xffffu) | ((unsigned)smp[2 * k + 1] << 16));
         }
         __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the 16 lanes of the wave see lane 0's LDS writes (in-order LDS)
         typedef __attribute__((address_space(3))) int *lds_ptr;

@@ -129,14 +129,15 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "nospec", "ldsq", "ldsq_cpw1"])
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "nospec", "exactq", "ldsq", "ldsq_cpw1"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
     fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
           "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP,
-          "nospec": batch.PLAN_NO_SPECULATION, "ldsq": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_4,
+          "nospec": batch.PLAN_NO_SPECULATION, "exactq": batch.PLAN_EXACT_QUOTIENT,
+          "ldsq": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_4,
           "ldsq_cpw1": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_1}[flags]
     shapes = [(2, 5300), (1, 41), (2, 20), (3, 999), (2, 12000), (1, 6000), (8, 333), (2, 1), (1, 5120), (2, 5121),
               (5, 777), (2, 640), (1, 10240), (2, 319)]
@@ -418,22 +419,54 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     clips = [(0, 0, gpu.QoaDesc(2, 44100, n))]
     pcm = torch.from_numpy(fixture_pcm).cuda()
     outs = []
-    for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP):
+    for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT):
         plan = batch.EncodePlan(clips, flags)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
         declined, unpacked, misses = plan.stats()
+        cheap_declined = plan.stats4()[3]
         outs.append(out.cpu().numpy().tobytes())
+        if flags == batch.PLAN_EXACT_QUOTIENT:
+            assert cheap_declined == 0
+            continue
         if flags == batch.PLAN_DEFAULT:
-            print(f"fixture: {declined} declined + {unpacked} unpacked, {misses} speculation misses "
-                  f"of {2 * ((n + 19) // 20)} slices")
+            print(f"fixture: {declined} declined + {unpacked} unpacked, {misses} speculation misses, {cheap_declined} "
+                  f"cheap-quotient declines of {2 * ((n + 19) // 20)} slices")
+            # the cheap-quotient form must carry real music: a scalefactor-0 candidate's quotient wraps to the opposite sign
+            # in 0.6 % of the fixture's slices (tools/k1lab/wrap_study.c) and nearly all of those are proven losers in place
+            assert cheap_declined <= 2 * ((n + 19) // 20) // 50
             assert declined + unpacked <= 2 * ((n + 19) // 20) // 200
             assert 0 < misses <= 2 * ((n + 19) // 20) // 20  # tonal passages: a few per cent, never the bulk
         elif flags == batch.PLAN_NO_SPECULATION:
             assert misses == 0 and declined + unpacked <= 2 * ((n + 19) // 20) // 200
         else:
             assert (declined, unpacked, misses) == (0, 0, 0)
-    assert outs[0] == outs[1] == outs[2] == oracle.encode_all(fixture_pcm, 2, 44100, n)
+    assert outs[0] == outs[1] == outs[2] == outs[3] == oracle.encode_all(fixture_pcm, 2, 44100, n)
+
+
+@pytest.mark.parametrize("gain", [1.5, 3.0, 8.0])
+def test_cheap_quotient_on_loud_material(gpu, oracle, fixture_pcm, gain):
+    """The cheap-quotient step form (level from |n|, sign from the residual) against its hard case: amplified, clipped music,
+    where the scalefactor-0 candidate's quotient wraps to the opposite sign in 5-25 % of the slices (tools/k1lab/wrap_study.c).
+    Marked candidates must be proven losers or the slice repeated with the exact qoa_div: bytes equal the oracle's and the
+    exact-quotient form's, and the decline path is actually taken."""
+    from qoaudio_amd import batch
+    n = min(len(fixture_pcm) // 2, 40 * 5120)
+    x = np.clip(np.rint(fixture_pcm[:2 * n].astype(np.float64) * gain), -32768, 32767).astype(np.int16)
+    clips = [(0, 0, gpu.QoaDesc(2, 44100, n))]
+    pcm = torch.from_numpy(x).cuda()
+    outs, declines = [], []
+    for flags in (batch.PLAN_DEFAULT, batch.PLAN_EXACT_QUOTIENT, batch.PLAN_CPW_1):
+        plan = batch.EncodePlan(clips, flags)
+        out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
+        plan.run(pcm, out)
+        declines.append(plan.stats4()[3])
+        outs.append(out.cpu().numpy().tobytes())
+    assert outs[0] == outs[1] == outs[2] == oracle.encode_all(x, 2, 44100, n)
+    print(f"gain {gain}: cheap-quotient declines {declines[0]} of {2 * n // 20} slices")
+    assert declines[1] == 0
+    if gain >= 3.0:
+        assert declines[0] > 0
 
 
 def test_rank_ties_resolved_like_the_reference(gpu, oracle):

@@ -15,6 +15,11 @@ every ring register again holds the element it started with) and puts every wait
 import os
 
 SMP0, P, Q, T, U, SNEG, D, S0 = 96, 116, 118, 120, 121, 122, 123, 124
+# The LDS tile holds a slice's 20 samples as 10 i16 pairs (48-byte stride); they are read into v[SPK0:SPK0+9].  The
+# speculative forms use the pairs as they are (SDWA word selects, packed error terms); the others widen them into
+# v[SMP0:SMP0+19] first (unpack_samples: the pair registers are the upper half of that range, widened in place).
+SPK0 = SMP0 + 10
+RANK_EXACT_BELOW = 32767 * 32767   # saturating 32-bit rank of the speculative forms: below this value it is the true rank
 
 
 def step(i):
@@ -115,15 +120,24 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     P, Q, PR, T, U, SN, D, X, E = (f"v{r}" for r in (PK_P, PK_Q, PK_PR, PK_T, PK_U, PK_SN, PK_D, PK_X, PK_E))
     if N.get("alt") and i % 2:  # second temporary set: lets the scheduler overlap neighbouring steps
         P, Q, PR, T, U, SN, D, X, E = N["alt"]
+    sub_t = f"v_sub_u32 {T}, {smp}, {PR}"                  # residual
     if i == 0:
-        slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"
+        slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0" + N.get("fill", ""), f"v_mov_b32 {N['accb']}, 0" + N.get("fill", "")
+    elif spec:
+        if N.get("alt") and i % 4 == 0:
+            E = N["alt"][8]                                  # error pairs alternate between two registers
+        slot_a, slot_b = spec_rank_pair(i, N, B, E) if i % 2 == 0 else (None, None)
     else:
         slot_a = f"v_sub_u32 {E}, v{SMP0 + i - 1}, {RC[(i - 1) % 2]}"      # err of the previous step
         slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}"
+    if spec:
+        sub_t = spec_residual(i, T, PR)
     # Speculative form (spec): no penalty arithmetic at all; the weight energy is only sampled, at every 4th step, into a
-    # running maximum that the block loop tests after the slice (see pk_block).
+    # running maximum that the block loop tests after the slice (see pk_block).  Its samples stay i16 pairs and its rank is
+    # a saturating 32-bit sum formed two steps at a time (spec_rank_pair).
     pen_full = not spec
     check = spec and i % 4 == 0
+    cheap = bool(N.get("cheap"))
     L = [
         f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
         f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]" if pen_full or check else None,   # sum w^2 - (0x8ff << 18)
@@ -134,14 +148,15 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",  # (+-1, +-1) for B_n
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
         f"v_ashrrev_i32 {X}, 18, {Q}" if pen_full else None,
-        f"v_sub_u32 {T}, {smp}, {PR}",                      # residual
+        sub_t,
         slot_b,
         f"v_max_i32 {X}, 0, {X}" if pen_full else None,     # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
-        f"v_med3_i32 {T}, {T}, -1, 1",
+        f"v_med3_i32 {T}, {T}, -1, 1" if not cheap else f"v_ashrrev_i32 {SN}, 31, {T}",
         f"v_mad_i32_i24 {pen}, {X}, {X}, {pen}" if pen_full else None,
         (f"v_mov_b32 {N['qm']}, {Q}" if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
         f"v_ashrrev_i32 {U}, 16, {U}",
+    ] + ([
         f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
         f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled
         f"v_sub_u32 {T}, 0, {U}",
@@ -149,6 +164,14 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_max_i32 {T}, {U}, {T}",
         f"v_min_i32 {T}, 7, {T}",
         f"v_and_b32 {T}, 6, {T}",
+    ] if not cheap else [
+        # Cheap quotient (cheap_quotient_note): level from |n|, sign from the residual.  q = (n ^ s) - s is |n| whenever
+        # n and the residual do not have opposite signs, and negative when they do -- the flag pk_block looks for.
+        f"v_xor_b32 {U}, {U}, {SN}",
+        f"v_sub_u32 {U}, {U}, {SN}",
+        f"v_min_i32 {X}, 7, {U}",                           # kept for the flag OR of the step pair
+        f"v_and_b32 {T}, -10, {X}",                         # 2 * level (0xfffffff6: a negative q stays harmlessly wide)
+    ]) + [
         f"v_mad_u32_u24 {D}, {T}, %[c101], %[selb]",
         f"v_lshl_add_u32 {acc}, {acc}, 3, {T}",
         f"v_perm_b32 {D}, %[dqhi], %[dqlo], {D}",
@@ -163,21 +186,70 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
     ]
     L = [l for l in L if l is not None]
-    assert len(L) == (35 if not spec else 33 if check else 30)
-    if i == 1:  # |err| of the first sample, right after slot_a produced it
-        k = L.index(slot_a) + 1
-        L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
+    if not spec:
+        assert len(L) == 35
+        if i == 1:  # |err| of the first sample, right after slot_a produced it
+            k = L.index(slot_a) + 1
+            L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
+    else:
+        assert len(L) == (25 if cheap else 28) + (3 if check else 0) + (2 if i % 2 == 0 else 0)
+        if i == 2:
+            k = L.index(slot_b) + 1
+            L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
+        if cheap and i % 2:                                  # flag OR over this step and the one before it
+            xp, xa = f"v{PK_X}", N["alt"][7]
+            L.append((f"v_or_b32 {CH_W}, {xp}, {xa}" if i == 1 else f"v_or3_b32 {CH_W}, {CH_W}, {xp}, {xa}") + N.get("fill", ""))
     return L
 
 
-def pk_step_ldsq(i, N):
+def cheap_quotient_note():
+    """Why the cheap form is exact.  The reference's quantiser input is r = n + sgn(v) - sgn(n) (qoa_div, src/lib.rs:613-617)
+    with n the rounded quotient in wrapping i32 arithmetic -- the steps compute the very same n.  Only min(|r|, 7) & 6 (the
+    level) and the sign of r are used (src/lib.rs:569-571, QOA_QUANT_TAB).  Unless n and v have strictly opposite signs,
+    |r| = max(|n|, [v != 0]) -- same level as |n|, because 0 and 1 share level 0 -- and r is negative exactly when v is.
+    Opposite signs need the product to wrap, |v| * recip >= 2^31 - 2^15: only scalefactors 0 and 1 can (|v| <= 295 k with
+    i16 weights and history), and then q < 0 marks the lane.  A marked candidate is taken out of the election; what is left
+    to show is that it would have lost: up to the marked step its state is exact, and at that step |v| >= 32768 with a
+    dequantised value of at most 49, so its true error there is at least min(32719, 32767 - max|sample of the slice|)
+    (either the reconstruction is within 49 of the prediction, or it sits on the rail opposite to v).  The square of that
+    bound comes with the slice's samples (BOUND_IN); the winner's rank must be below it, else the slice is declined."""
+
+
+def spec_residual(i, T, PR):
+    """sample i of the slice is half (i & 1) of pair register i >> 1"""
+    return (f"v_sub_u32_sdwa {T}, sext(v{SPK0 + i // 2}), {PR} dst_sel:DWORD dst_unused:UNUSED_PAD "
+            f"src0_sel:WORD_{i % 2} src1_sel:DWORD")
+
+
+def spec_rank_pair(i, N, B, E):
+    """Error terms of samples i-2, i-1 in two instructions: B (the newest history pair at step i) holds exactly their
+    reconstructions, so (err, err) = sample pair - B, saturated to i16, and rank += err.err, saturated to i32.  Both
+    saturations only ever make the sum SMALLER than the true rank but never below 32767^2 once they act, so a rank below
+    that value is exact and any other is at least that large (pk_block tests the winner's)."""
+    elo = N["e"].split(":")[0].replace("v[", "v")
+    return (f"v_pk_sub_i16 {E}, v{SPK0 + i // 2 - 1}, {B} clamp" + N.get("fill", ""),
+            f"v_dot2_i32_i16 {elo}, {E}, {E}, {'0' if i == 2 else elo} clamp" + N.get("fill", ""))
+
+
+def spec_aerr0(N, E, X):
+    """|err| of the first sample (orders the first-sample ranks) from the low half of the first error pair"""
+    return [l + N.get("fill", "") for l in (f"v_bfe_i32 {X}, {E}, 0, 16", f"v_sub_u32 {N['aerr0']}, 0, {X}",
+                                            f"v_max_i32 {N['aerr0']}, {X}, {N['aerr0']}")]
+
+
+ELO_REG = "v82"   # the block loops' rank register (PK_FIXED e = v[82:83]; the speculative forms use the low dword only)
+
+
+def pk_step_ldsq(i, N, deferred=None):
     """Speculative step with the quantiser in an LDS table (BASELINE.json's "tables staged in LDS"): for batches that give
     every SIMD several wavefronts, where the ~100 cycles of the lookup are covered by the other wavefronts and what counts
     is the issue-slot total.  scaled -> clamp(-8, 8) -> entry [sf][c + 8] = dequant & 0xffff | code << 29 replaces the
     closed-form quantiser + v_perm dequant + sign fix-ups of pk_step(): 22 (25 at a sampling step) VALU + 1 LDS read
     instead of 30 (33).  Same values: QOA_QUANT_TAB / QOA_DEQUANT_TAB (src/lib.rs:22, :847-864) are what the closed form
     was derived from.  The order below keeps the v_dot2 / v_pk wait states by construction (not list-scheduled: the
-    read's wait is a fence, and with other wavefronts filling the slots dependent issue costs nothing)."""
+    read's wait is a fence, and with other wavefronts filling the slots dependent issue costs nothing).
+    Returns (lines, acc_line): the slice-word accumulate of this step is handed to the NEXT step (`deferred`), which issues
+    it in the wait states behind its v_dot2 pair -- at odd steps nothing else is left to fill them."""
     R, S, RC = N["R"], PK_S, PK_RC
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
@@ -189,8 +261,7 @@ def pk_step_ldsq(i, N):
     if i == 0:
         slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"
     else:
-        slot_a = f"v_sub_u32 {E}, v{SMP0 + i - 1}, {RC[(i - 1) % 2]}"      # err of the previous step
-        slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}"
+        slot_a, slot_b = spec_rank_pair(i, N, B, E) if i % 2 == 0 else (None, None)
     check = i % 4 == 0
     L = [
         f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
@@ -200,8 +271,9 @@ def pk_step_ldsq(i, N):
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",
         slot_a,
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",
+        deferred,
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
-        f"v_sub_u32 {T}, {smp}, {PR}",                      # residual
+        spec_residual(i, T, PR),
         slot_b,
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1",
@@ -213,19 +285,19 @@ def pk_step_ldsq(i, N):
         f"v_lshl_add_u32 {X}, {U}, 2, %[qtab]",
         f"ds_read_b32 {X}, {X}",
         "s_waitcnt lgkmcnt(0)",
-        f"v_alignbit_b32 {acc}, {acc}, {X}, 29",            # slice = slice << 3 | code (:584)
         f"v_add_u32_sdwa {U}, {PR}, sext({X}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0",
         f"v_bfe_i32 {D}, {X}, 4, 12",                       # delta = dequantised >> 4 (:822)
         f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
+        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
+    ] + ([f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {Bn} clamp"] if i == 19 else []) + [   # the last error pair (spec_rank_pair)
         f"v_pk_mad_i16 {w01}, {SA}, {D}, {w01} op_sel_hi:[1,0,1]",
         f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
-        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
-    ]
+    ] + ([f"v_dot2_i32_i16 {ELO_REG}, {E}, {E}, {ELO_REG} clamp"] if i == 19 else [])
     L = [l for l in L if l is not None]
-    if i == 1:  # |err| of the first sample, right after slot_a produced it
-        k = L.index(slot_a) + 1
-        L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
-    return L
+    if i == 2:
+        k = L.index(slot_b) + 1
+        L[k:k] = spec_aerr0(N, E, f"v{PK_D}")               # (temporary: D; X still holds step 1's table word)
+    return L, f"v_alignbit_b32 {acc}, {acc}, {X}, 29"       # slice = slice << 3 | code (:584)
 
 
 def pk_zero(N):
@@ -244,15 +316,30 @@ def pk_prologue(N, zero=True):
 
 
 def sample_reads(addr):
-    return [f"ds_read_b128 v[{SMP0 + 4 * k}:{SMP0 + 4 * k + 3}], {addr} offset:{16 * k}" for k in range(5)]
+    """a slice's tile record: dword 0 = BOUND_IN (see pk_block, cheap form), dword 1 unused, dwords 2..11 the sample pairs"""
+    return [f"ds_read_b128 v[{SPK0 - 2}:{SPK0 + 1}], {addr} offset:0",
+            f"ds_read_b128 v[{SPK0 + 2}:{SPK0 + 5}], {addr} offset:16",
+            f"ds_read_b128 v[{SPK0 + 6}:{SPK0 + 9}], {addr} offset:32"]
+
+
+BOUND_IN = f"v{SPK0 - 2}"
+# extra fixed registers of the cheap-quotient form (v96..v103 are free in the speculative forms: no widened samples)
+CH_W, CH_TMP, CH_BIG, CH_BND = "v96", "v97", "v98", "v99"
+
+
+def unpack_samples():
+    """i16 pairs v[SPK0 + k] -> sign-extended v[SMP0 + 2k], v[SMP0 + 2k + 1]; in place: pair k is read before the two
+    registers written for it can reach an unread pair (SMP0 + 2k + 1 <= SPK0 + k for k <= 9)."""
+    L = []
+    for k in range(10):
+        L += [f"v_bfe_i32 v{SMP0 + 2 * k}, v{SPK0 + k}, 0, 16", f"v_ashrrev_i32 v{SMP0 + 2 * k + 1}, 16, v{SPK0 + k}"]
+    return L
 
 
 def pk_slice():
     N = PK_OPERANDS
-    lines = sample_reads("%[tile]") + pk_prologue(N)
+    lines = sample_reads("%[tile]") + pk_prologue(N) + ["s_waitcnt lgkmcnt(0)"] + unpack_samples()
     for i in range(20):
-        if i % 4 == 0:
-            lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
         lines += pk_step(i, N)
     lines += [f"v_sub_u32 v{PK_E}, v{SMP0 + 19}, {PK_RC[1]}", f"v_mad_i64_i32 {N['e']}, vcc, v{PK_E}, v{PK_E}, {N['e']}"]
     return lines
@@ -267,11 +354,15 @@ def pk_slice():
 #   v_dot2 result -> overwritten by another VALU: 4 between;  packed (v_pk_*) result -> any VALU read: 1 between.
 import re
 
-_MOD = re.compile(r"\b(op_sel_hi|op_sel|row_ror|row_mask|bank_mask|offset):(\[[^\]]*\]|\S+)")
+_MOD = re.compile(r"\b(op_sel_hi|op_sel|row_ror|row_mask|bank_mask|offset|dst_sel|dst_unused|src0_sel|src1_sel):(\[[^\]]*\]|\S+)"
+                  r"|\bclamp\b")
 
 
 def _regs(tok):
     tok = tok.strip()
+    m = re.fullmatch(r"sext\((.*)\)", tok)
+    if m:
+        tok = m.group(1)
     m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
     if m:
         return [f"v{k}" for k in range(int(m.group(1)), int(m.group(2)) + 1)]
@@ -292,8 +383,16 @@ def _parse(line):
     return op, dst, src, acc
 
 
+FILL = "  #fill"   # tag: off-chain work the scheduler keeps back for slots where nothing else may issue (see schedule)
+
+
 def schedule(lines):
+    """Lines tagged FILL (the speculative form's rank terms: nothing on the serial chain waits for them) are only issued
+    when no untagged instruction may issue -- they fill the wait states behind the prediction's v_dot2 pair instead of
+    being spent on soft (back-to-back) gaps, which would leave an s_nop there."""
     n = len(lines)
+    fill = [l.endswith(FILL) for l in lines]
+    lines = [l[:-len(FILL)] if f else l for l, f in zip(lines, fill)]
     info = [_parse(l) for l in lines]
     hard = [dict() for _ in range(n)]   # hard[j][i] = minimum distance j - i
     soft = [dict() for _ in range(n)]
@@ -306,13 +405,16 @@ def schedule(lines):
             if r in last_write:
                 i = last_write[r]
                 pop = info[i][0]
+                sft = 2
                 if pop.startswith("v_dot2"):
                     h = 1 if (op == pop and r in acc) else 4
+                    if h == 1:
+                        sft = 1     # accumulator chaining is forwarded: keep the fillers for the 3-slot gap behind the pair
                 elif pop.startswith("v_pk_"):
                     h = 2
                 else:
                     h = 1
-                need(i, h, 2)
+                need(i, h, sft)
         for r in dst:
             if r in last_write:
                 i = last_write[r]
@@ -341,8 +443,16 @@ def schedule(lines):
             order.append("s_nop 0")
             t += 1
             continue
-        good = [j for j in ok if all(t - pos[i] >= d for i, d in soft[j].items())]
-        j = max(good or ok, key=lambda k: (prio[k], -k))
+        main = [j for j in ok if not fill[j]]
+        spare = sorted(j for j in ok if fill[j])
+        good = [j for j in main if all(t - pos[i] >= d for i, d in soft[j].items())]
+        if good:
+            j = max(good, key=lambda k: (prio[k], -k))
+        elif main and len(spare) < 2:
+            j = max(main, key=lambda k: (prio[k], -k))
+        else:
+            j = spare[0]  # oldest filler first (its source registers are the next to be recycled); with two or more in
+                          # hand one may also go into a soft gap -- one stays in reserve for the next hard gap
         pos[j] = t
         order.append(lines[j])
         t += 1
@@ -356,7 +466,7 @@ def schedule(lines):
     return order, back_to_back
 
 
-def pk_block(verbose=False, spec=False, ldsq=False):
+def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -381,12 +491,18 @@ def pk_block(verbose=False, spec=False, ldsq=False):
     SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
     CANDC, PADDR, THR, QM = "v65", "v64", "v119", N["qm"]
     cand = CANDC if spec else "%[cand]"
+    reads = sample_reads(TCUR)
+    if spec:
+        K1 = ELO
     prev = PADDR if spec else ADDR
     dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
-    zero = [f"v_mov_b64 {N['e']}, 0"] + ([] if spec else [f"v_mov_b32 {N['pen']}, 0"])
+    # full form: rank and penalty sums are cleared for the next slice; the speculative rank starts from an inline 0
+    zero = [] if spec else [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0"]
+    assert ELO == ELO_REG
     L = []
     L += [
         "s_mov_b32 s95, 0x10001",
+    ] + ([f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW:x}"] if spec else []) + ([f"v_mov_b32 {CH_BIG}, 0x7fffffff"] if cheap else []) + [
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an early exit restores
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
@@ -400,13 +516,31 @@ def pk_block(verbose=False, spec=False, ldsq=False):
     body = pk_prologue(N, zero=False)                        # rank and penalty sums are cleared in the election's gaps
     if ldsq:
         N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
+    elif spec:
+        N = dict(N, fill=FILL, cheap=cheap)
+    acc_line = None
     for i in range(20):
-        body += pk_step_ldsq(i, N) if ldsq else pk_step(i, N, spec)
-    E = f"v{PK_E}" if ldsq else N["alt"][8]                  # step 19 used the second temporary set
-    body += [
-        f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
-        f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
-    ] + ([] if spec else [f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}"])   # total rank = sum err^2 + sum penalty^2
+        if ldsq:
+            lines, acc_line = pk_step_ldsq(i, N, acc_line)
+            body += lines
+        else:
+            body += pk_step(i, N, spec)
+    if ldsq:
+        body.append(acc_line)
+    if not spec:
+        E = N["alt"][8]                                      # step 19 used the second temporary set
+        body = unpack_samples() + body + [
+            f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
+            f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
+            f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
+        ]
+    elif not ldsq:
+        E = N["alt"][8]                                      # pair 9: the odd pairs' register (pk_step)
+        body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,       # the last error pair (spec_rank_pair)
+                 f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL,
+                 f"v_cmp_ge_i32 vcc, {QM}, %[limq]" + FILL]    # the first test below, as one more filler
+        if cheap:
+            body.append(f"v_mov_b32 {CH_BND}, s94" + FILL)   # the winner's rank limit when no candidate is marked
     if ldsq:
         b2b = -1                                             # kept in program order (see pk_step_ldsq)
     else:
@@ -415,37 +549,49 @@ def pk_block(verbose=False, spec=False, ldsq=False):
         print(f"block body{' (speculative)' if spec else ''}: {len(body)} instructions after scheduling, "
               f"{b2b} consumers directly behind their producer")
     L += body
-    L += [
-        f"v_cmp_ge_i32 vcc, {QM}, %[limq]" if spec else f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
+    L += ([] if spec and not ldsq else
+          [f"v_cmp_ge_i32 vcc, {QM}, %[limq]" if spec else f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]"]) + [
         "s_cbranch_vccnz Lqoa_declined_%=",
-    ] + ([f"v_xor_b32 {CANDC}, %[pp], {CANDC}"] if spec else []) + [   # the other slot buffer: the entry state stays put
+    ] + ([
+        f"v_cmp_gt_i32 vcc, 0, {CH_W}",                      # any candidate marked (cheap_quotient_note)?
+        "s_cbranch_vccnz Lqoa_marked_%=",
+        "Lqoa_unmarked_%=:",
+    ] if cheap else []) + ([f"v_xor_b32 {CANDC}, %[pp], {CANDC}"] if spec else []) + ([   # the other slot buffer: the entry state stays put
+        # keys of the full form: rank < 2^37 -> rank >> 5, then rank[7:0] : |err0| : sf << 4
         f"ds_write_b128 {cand}, v[84:87]",
         f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
         f"v_lshlrev_b32 {K2}, 24, {ELO}",
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, {K2}",
         f"v_or_b32 {K2}, %[sf4], {K2}",
+    ] if not spec else [
+        # speculative form: the saturating rank is one dword; second key |err0| : sf << 4
+        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, %[sf4]",
+    ]) + [
         f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
         f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
         dpp(M, 4),
         f"v_or_b32 {SHI}, %[sfsh], {SHI}",
-        f"v_add_u32 {TCUR}, 80, {TCUR}",
+        f"v_add_u32 {TCUR}, 48, {TCUR}",
         dpp(M, 2),
-        f"ds_read_b128 v[{SMP0}:{SMP0 + 3}], {TCUR} offset:0",
-        f"ds_read_b128 v[{SMP0 + 4}:{SMP0 + 7}], {TCUR} offset:16",
+        reads[0],
+        reads[1],
         dpp(M, 1),
         f"v_cmp_eq_u32 vcc, {K1}, {M}",
         f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
-        f"ds_read_b128 v[{SMP0 + 8}:{SMP0 + 11}], {TCUR} offset:32",
-        f"ds_read_b128 v[{SMP0 + 12}:{SMP0 + 15}], {TCUR} offset:48",
-        dpp(K2, 8),
-        f"ds_read_b128 v[{SMP0 + 16}:{SMP0 + 19}], {TCUR} offset:64",
+        reads[2],
         f"v_add_u32 {OCUR}, 8, {OCUR}",
+        dpp(K2, 8),
+        f"ds_write_b128 {cand}, v[84:87]" if spec else "s_nop 0",
+        "s_nop 0",
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
         "s_cmp_lt_u32 %[done], %[n]",
         dpp(K2, 2),
-    ] + (zero if not spec else zero + ["s_nop 0"]) + [       # for the next slice; e (and pen) are dead by now
+    ] + (zero if not spec else [                             # full form: clear e and pen for the next slice (dead by now)
+        f"v_cmp_le_u32 vcc, {CH_BND if cheap else 's94'}, {M}",   # speculative form: is the winner's rank its true rank?
+        "s_cbranch_vccnz Lqoa_late_%=",                      # (see spec_rank_pair; the slice then goes to the full form)
+    ]) + [
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {cand}",           # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
@@ -460,7 +606,12 @@ def pk_block(verbose=False, spec=False, ldsq=False):
     ] if spec else []) + [
         "s_cbranch_scc1 Lqoa_top_%=",
         "s_branch Lqoa_end_%=",
-    ] + (["Lqoa_late_%=:", "s_sub_u32 %[done], %[done], 1"] if spec else []) + [
+    ] + ([
+        "Lqoa_marked_%=:",
+        f"v_cndmask_b32 {ELO}, {ELO}, {CH_BIG}, vcc",        # marked candidates leave the election ...
+        f"v_mov_b32 {CH_BND}, {BOUND_IN}",                   # ... and the winner must beat what they provably cost
+        "s_branch Lqoa_unmarked_%=",
+    ] if cheap else []) + (["Lqoa_late_%=:", "s_sub_u32 %[done], %[done], 1"] if spec else []) + [
         "Lqoa_declined_%=:",
         f"ds_read_b128 v[84:87], {prev}",                    # entry state of the declined slice
         "Lqoa_end_%=:",
@@ -478,14 +629,14 @@ def render(verbose=False):
     for j in range(4):
         lines += [f"v_ashrrev_i32 v{S0 + j}, 31, %[h{j}]", f"v_or_b32 v{S0 + j}, 1, v{S0 + j}"]
     lines += ["v_mov_b64 %[e], 0", "v_mov_b32 %[pen], 0", "v_mov_b32 %[acca], 0", "v_mov_b32 %[accb], 0"]
+    lines += ["s_waitcnt lgkmcnt(0)"] + unpack_samples()
     for i in range(20):
-        if i % 4 == 0:
-            lines.append(f"s_waitcnt lgkmcnt({4 - i // 4})")
         lines += step(i)
     pk = pk_slice()
     blk = pk_block(verbose)
     blk_spec = pk_block(verbose, spec=True)
     blk_ldsq = pk_block(verbose, spec=True, ldsq=True)
+    blk_cheap = pk_block(verbose, spec=True, cheap=True)
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
@@ -497,8 +648,11 @@ def render(verbose=False):
            + emit("QOA_BLOCK_PK_ASM_TEXT", blk) + "\n" + emit("QOA_BLOCK_SPEC_ASM_TEXT", blk_spec) + "\n"
            + "// QOA_BLOCK_SPEC_LDSQ_ASM_TEXT: the speculative loop with the quantiser + dequantiser in an LDS table (22/25\n"
            + "//   VALU + 1 LDS read per step): for launches that give every SIMD several wavefronts.\n"
-           + emit("QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", blk_ldsq))
-    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq))
+           + emit("QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", blk_ldsq) + "\n"
+           + "// QOA_BLOCK_CHEAP_ASM_TEXT: the speculative loop with the cheap quotient (25/28 VALU per step; level from |n|, sign\n"
+           + "//   from the residual, candidates whose quotient wrapped to the opposite sign are marked and proven losers).\n"
+           + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap))
+    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap))
 
 
 INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
