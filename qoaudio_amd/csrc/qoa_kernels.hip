@@ -443,7 +443,8 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlockSlices = 16;
 constexpr unsigned kSpecCooldownBlocks = 4; // blocks on the full step form after a speculation miss (misses cluster)
-constexpr unsigned kCheapCooldownBlocks = 2; // blocks on the exact-quotient form after the cheap-quotient form declined a slice
+constexpr unsigned kCheapCooldownBlocks = 4; // blocks on the exact-quotient form once the cheap-quotient form declined slices
+                                             // in two consecutive blocks (or twice in one)
 // A slice's tile record is 12 dwords (three ds_read_b128): [0] marked_bound() of the slice, [1] unused, [2..11] its 20
 // samples as 10 i16 pairs.  One record of slack: the block loops prefetch one slice past their last.  (17 * 12 = 204 dwords:
 // the 4 chain tiles of a wave start 12 banks apart.)
@@ -563,7 +564,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     int limq, winq;
     spec_limits(sf, limq, winq);
     unsigned spec_cooldown = 0;  // blocks left on the full form after a speculation miss (wave-uniform)
-    unsigned cheap_cooldown = 0; // blocks left on the exact-quotient speculative form after the cheap one declined a slice
+    unsigned cheap_cooldown = 0; // blocks left on the exact-quotient speculative form after the cheap one declined slices
+    unsigned last_cheap_decline = 0xfffffff0u; // block of the cheap form's last decline (wave-uniform)
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -637,19 +639,26 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                         j = run_block_spec_ldsq(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, qtab_addr,
                                                 kBlockSlices, pk);
                     } else {
-                        if (allow_cheap && cheap_cooldown == 0) {
-                            j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq,
-                                                     kBlockSlices, pk);
-                            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-                            if (j < kBlockSlices) { // loud passage (or a genuine miss): the exact quotient for a while
-                                cheap_cooldown = kCheapCooldownBlocks + 1;
+                        // cheap quotient first; a slice it declines is repeated with the exact quotient and the cheap form takes
+                        // the block up again behind it -- unless declines come in quick succession (a loud passage)
+                        bool proven = true;
+                        while (j < kBlockSlices && proven) {
+                            const bool cheap = allow_cheap && cheap_cooldown == 0;
+                            if (cheap) {
+                                j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
+                                                          dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk);
+                                j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+                                if (j == kBlockSlices) break;
                                 if (stats && sf == 0) atomicAdd(&stats[3], 1ull);
+                                if (blk - last_cheap_decline <= 1u) cheap_cooldown = kCheapCooldownBlocks + 1;
+                                last_cheap_decline = blk;
                             }
-                        }
-                        if (j < kBlockSlices) {
-                            const unsigned j0 = j;
-                            j += run_block_spec<false>(tile0 + 4u * kSliceDwords * j0, cand_addr, kCandBufBytes, outb_addr + 8u * j0,
-                                                       dummy_addr, sf, kc, limq, winq, kBlockSlices - j0, pk);
+                            const unsigned n_exact = cheap && cheap_cooldown == 0 ? 1u : kBlockSlices - j;
+                            unsigned r = run_block_spec<false>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes,
+                                                               outb_addr + 8u * j, dummy_addr, sf, kc, limq, winq, n_exact, pk);
+                            r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+                            j += r;
+                            proven = r == n_exact;
                         }
                     }
                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: all forms return an SGPR)

@@ -155,7 +155,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_med3_i32 {T}, {T}, -1, 1" if not cheap else f"v_ashrrev_i32 {SN}, 31, {T}",
         f"v_mad_i32_i24 {pen}, {X}, {X}, {pen}" if pen_full else None,
         (f"v_mov_b32 {N['qm']}, {Q}" if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
-        f"v_ashrrev_i32 {U}, 16, {U}",
+        f"v_ashrrev_i32 {U}, 16, {U}" if not cheap else None,
     ] + ([
         f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
         f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled
@@ -167,8 +167,9 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     ] if not cheap else [
         # Cheap quotient (cheap_quotient_note): level from |n|, sign from the residual.  q = (n ^ s) - s is |n| whenever
         # n and the residual do not have opposite signs, and negative when they do -- the flag pk_block looks for.
+        # n = product >> 16 is taken by the SDWA word select: (product ^ s) >> 16 == (product >> 16) ^ s for s in {0, -1}.
         f"v_xor_b32 {U}, {U}, {SN}",
-        f"v_sub_u32 {U}, {U}, {SN}",
+        f"v_sub_u32_sdwa {U}, sext({U}), {SN} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD",
         f"v_min_i32 {X}, 7, {U}",                           # kept for the flag OR of the step pair
         f"v_and_b32 {T}, -10, {X}",                         # 2 * level (0xfffffff6: a negative q stays harmlessly wide)
     ]) + [
@@ -178,13 +179,22 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_sub_u32 {acc}, {acc}, {SN}",
         f"v_xor_b32 {D}, {D}, {SN}",
         f"v_sub_u32 {D}, {D}, {SN}",                        # dequantised
+    ] + ([
         f"v_add_u32 {U}, {D}, {PR}",
         f"v_ashrrev_i32 {D}, 4, {D}",                       # delta
         f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
         f"v_pk_mad_i16 {w01}, {SA}, {D}, {w01} op_sel_hi:[1,0,1]",
         f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
         f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
-    ]
+    ] if not spec else [
+        # speculative forms: the unclamped reconstruction goes to RC[i % 2]; B_(n+1) = (sat16(previous), sat16(this)) is one
+        # v_cvt_pk_i16_i32 (clamping the previous value again gives the same i16) -- no v_med3 + v_alignbit
+        f"v_add_u32 {rc}, {D}, {PR}",
+        f"v_ashrrev_i32 {D}, 4, {D}",                       # delta
+        f"v_pk_mad_i16 {w01}, {SA}, {D}, {w01} op_sel_hi:[1,0,1]",
+        f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
+        f"v_cvt_pk_i16_i32 {Bn}, {RC[(i + 1) % 2]}, {rc}",
+    ])
     L = [l for l in L if l is not None]
     if not spec:
         assert len(L) == 35
@@ -192,7 +202,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
-        assert len(L) == (25 if cheap else 28) + (3 if check else 0) + (2 if i % 2 == 0 else 0)
+        assert len(L) == (23 if cheap else 27) + (3 if check else 0) + (2 if i % 2 == 0 else 0)
         if i == 2:
             k = L.index(slot_b) + 1
             L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
@@ -285,12 +295,11 @@ def pk_step_ldsq(i, N, deferred=None):
         f"v_lshl_add_u32 {X}, {U}, 2, %[qtab]",
         f"ds_read_b32 {X}, {X}",
         "s_waitcnt lgkmcnt(0)",
-        f"v_add_u32_sdwa {U}, {PR}, sext({X}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0",
+        f"v_add_u32_sdwa {rc}, {PR}, sext({X}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0",
         f"v_bfe_i32 {D}, {X}, 4, 12",                       # delta = dequantised >> 4 (:822)
-        f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
-        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",              # B_(n+1) = (h[n-1], recon)
-    ] + ([f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {Bn} clamp"] if i == 19 else []) + [   # the last error pair (spec_rank_pair)
+        f"v_cvt_pk_i16_i32 {Bn}, {RC[(i + 1) % 2]}, {rc}",  # B_(n+1) = (h[n-1], recon), both clamped (see pk_step)
         f"v_pk_mad_i16 {w01}, {SA}, {D}, {w01} op_sel_hi:[1,0,1]",
+    ] + ([f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {Bn} clamp"] if i == 19 else []) + [   # the last error pair (spec_rank_pair)
         f"v_pk_mad_i16 {w23}, {SB}, {D}, {w23} op_sel_hi:[1,0,1]",
     ] + ([f"v_dot2_i32_i16 {ELO_REG}, {E}, {E}, {ELO_REG} clamp"] if i == 19 else [])
     L = [l for l in L if l is not None]
@@ -304,9 +313,9 @@ def pk_zero(N):
     return [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0"]
 
 
-def pk_prologue(N, zero=True):
+def pk_prologue(N, zero=True, spec=False):
     R, S = N["R"], PK_S
-    return [
+    return ([f"v_ashrrev_i32 {PK_RC[1]}, 16, {R[0]}"] if spec else []) + [   # h3: step 0's "previous reconstruction"
         f"v_alignbit_b32 {R[3]}, {R[0]}, {R[2]}, 16",        # B_(-1) = (h1, h2)
         f"v_pk_ashrrev_i16 {S[2]}, 15, {R[2]} op_sel_hi:[0,1]",
         f"v_pk_ashrrev_i16 {S[3]}, 15, {R[3]} op_sel_hi:[0,1]",
@@ -410,7 +419,7 @@ def schedule(lines):
                     h = 1 if (op == pop and r in acc) else 4
                     if h == 1:
                         sft = 1     # accumulator chaining is forwarded: keep the fillers for the 3-slot gap behind the pair
-                elif pop.startswith("v_pk_"):
+                elif pop.startswith("v_pk_") or pop.startswith("v_cvt_pk"):
                     h = 2
                 else:
                     h = 1
@@ -513,7 +522,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         "Lqoa_top_%=:",
         "s_waitcnt lgkmcnt(1)",                              # the winner's state (only a slice-word store may trail)
     ]
-    body = pk_prologue(N, zero=False)                        # rank and penalty sums are cleared in the election's gaps
+    body = pk_prologue(N, zero=False, spec=spec)             # rank and penalty sums are cleared in the election's gaps
     if ldsq:
         N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
     elif spec:

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""K1 step forms side by side on config 3's signal (1024 stereo clips, FRAMES frames each): kernel time and the counters of
+qoa_encode_plan_stats4 per plan flag set.  Run on the GPU box:  python tools/k1lab/forms.py [frames]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from qoaudio_amd import batch, synth  # noqa: E402
+import qoaudio_amd as gpu  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n_clips, ch = 1024, 2
+samples = frames * 5120
+pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda")
+per = samples * ch
+enc = gpu.encoded_size(ch, samples)
+clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
+ref = None
+for name, fl in (("default (cheap quotient)", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT),
+                 ("no speculation", batch.PLAN_NO_SPECULATION), ("lds tables", batch.PLAN_LDS_TABLES)):
+    plan = batch.EncodePlan(clips, fl)
+    out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
+    plan.run(pcm.view(-1), out)
+    torch.cuda.synchronize()
+    s0 = plan.stats4()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        plan.run(pcm.view(-1), out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    if ref is None:
+        ref = out.clone()
+    same = bool(torch.equal(ref, out))
+    slices = n_clips * ch * frames * 256
+    print(f"{name:28s} {ms:8.3f} ms  {ms * 1e6 / (frames * 256):7.1f} ns/slice  declined/unpacked/spec-miss/cheap-declined "
+          f"{s0} of {slices} slices  bytes equal: {same}")
