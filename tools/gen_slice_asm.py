@@ -138,6 +138,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     pen_full = not spec
     check = spec and i % 4 == 0
     cheap = bool(N.get("cheap"))
+    A1 = CH_A1[i % 2]
     L = [
         f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
         f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]" if pen_full or check else None,   # sum w^2 - (0x8ff << 18)
@@ -164,12 +165,22 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_max_i32 {T}, {U}, {T}",
         f"v_min_i32 {T}, 7, {T}",
         f"v_and_b32 {T}, 6, {T}",
+    ] if not spec else [
+        # speculative form, exact quotient: |scaled| and the dequantised value's sign as multiplications by a1 = +-1
+        f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
+        f"v_med3_i32 {U}, {U}, {SN}, {T}",                  # scaled
+        f"v_ashrrev_i32 {SN}, 31, {U}",
+        f"v_or_b32 {A1}, 1, {SN}",
+        f"v_mul_i32_i24 {T}, {U}, {A1}",                    # |scaled| (< 2^17)
+        f"v_min_i32 {T}, 7, {T}",
+        f"v_and_b32 {T}, 6, {T}",
     ] if not cheap else [
         # Cheap quotient (cheap_quotient_note): level from |n|, sign from the residual.  q = (n ^ s) - s is |n| whenever
         # n and the residual do not have opposite signs, and negative when they do -- the flag pk_block looks for.
-        # n = product >> 16 is taken by the SDWA word select: (product ^ s) >> 16 == (product >> 16) ^ s for s in {0, -1}.
-        f"v_xor_b32 {U}, {U}, {SN}",
-        f"v_sub_u32_sdwa {U}, sext({U}), {SN} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD",
+        # Both sign changes are multiplications by a1 = +-1 (= s | 1): q = n * a1, with n = product >> 16 taken by the SDWA
+        # word select, and further down dequantised = magnitude * a1.
+        f"v_or_b32 {A1}, 1, {SN}",
+        f"v_mul_i32_i24_sdwa {U}, sext({U}), {A1} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD",
         f"v_min_i32 {X}, 7, {U}",                           # kept for the flag OR of the step pair
         f"v_and_b32 {T}, -10, {X}",                         # 2 * level (0xfffffff6: a negative q stays harmlessly wide)
     ]) + [
@@ -177,9 +188,12 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_lshl_add_u32 {acc}, {acc}, 3, {T}",
         f"v_perm_b32 {D}, %[dqhi], %[dqlo], {D}",
         f"v_sub_u32 {acc}, {acc}, {SN}",
+    ] + ([
         f"v_xor_b32 {D}, {D}, {SN}",
         f"v_sub_u32 {D}, {D}, {SN}",                        # dequantised
-    ] + ([
+    ] if not spec else [
+        f"v_mul_i32_i24 {D}, {D}, {A1}",                    # dequantised
+    ]) + ([
         f"v_add_u32 {U}, {D}, {PR}",
         f"v_ashrrev_i32 {D}, 4, {D}",                       # delta
         f"v_med3_i32 {rc}, {U}, %[lo], %[hi]",              # reconstructed
@@ -202,7 +216,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
-        assert len(L) == (23 if cheap else 27) + (3 if check else 0) + (2 if i % 2 == 0 else 0)
+        assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (2 if i % 2 == 0 else 0)
         if i == 2:
             k = L.index(slot_b) + 1
             L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
@@ -334,6 +348,7 @@ def sample_reads(addr):
 BOUND_IN = f"v{SPK0 - 2}"
 # extra fixed registers of the cheap-quotient form (v96..v103 are free in the speculative forms: no widened samples)
 CH_W, CH_TMP, CH_BIG, CH_BND = "v96", "v97", "v98", "v99"
+CH_A1 = ["v100", "v101"]   # +-1 of the residual's sign, per temporary set
 
 
 def unpack_samples():
