@@ -59,12 +59,15 @@ def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
         return None, "traffic_stale: kernel sources changed since the PMC profile " + str(d.get("source"))
     return d[kernel]["traffic_bytes_per_launch"], None
 
-def valu_issue(n_chains: int, samples: int, kernel_ms: float, per_slice: float = 660.0):
+K1_VALU_PER_SLICE = 534.0  # PMC: SQ_INSTS_VALU / (wavefronts x slices) on config 3, profiles/r02_pmc_summary.txt
+
+
+def valu_issue(n_chains: int, samples: int, kernel_ms: float, per_slice: float = K1_VALU_PER_SLICE):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
-    Instruction count per slice is PMC-measured (SQ_INSTS_VALU / slices / waves): 660 for the register-table step form
-    (config 3, profiles/r02_pmc_summary.txt), 501 (+ 29 LDS) for the LDS-table form that launches with >= 2 wavefronts per
-    SIMD use (profiles/r02_pmc_summary.txt, full-chip note); a SIMD issues at most one instruction per 4 cycles whatever
-    the wavefront count (profiles/r02_ubench_gfx950_issue_classes.txt)."""
+    Instruction count per slice is PMC-measured (SQ_INSTS_VALU / slices / waves): 534 for the cheap-quotient register form
+    (config 3, profiles/r02_pmc_summary.txt; 523 in the block loop, the rest are the block tops; 660 at the start of round
+    2); the LDS-table form that launches with >= 8 wavefronts per SIMD use has 451 (+ 26 LDS) in its loop.  A SIMD issues at
+    most one instruction per 4 cycles whatever the wavefront count (profiles/r02_ubench_gfx950_issue_classes.txt)."""
     waves = (n_chains + 3) // 4
     slices = (samples + 19) // 20
     achieved = per_slice * slices * waves / (kernel_ms * 1e-3)
@@ -240,7 +243,7 @@ def main():
                      "traffic": enc_traffic, "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md",
-                     # the bound that actually governs K1 (profiles/r01i_pmc_summary.txt): 660 VALU wave-instructions
+                     # the bound that actually governs K1 (profiles/r02_pmc_summary.txt): 534 VALU wave-instructions
                      # per slice per wavefront, one per 4 cycles per SIMD at 2.4 GHz on 1024 SIMDs
                      "valu_issue": valu_issue(n_clips * ch, samples, k_avg_ms)},
     }
@@ -338,9 +341,10 @@ def main():
                                                                           args.rate, fc_samples)
         extras["full_chip"] = {"workload": f"{fc_clips} clips x {ch} ch x {fc_frames} frames (4 wavefronts per SIMD)",
                                "kernel_ms_avg": f_ms, "samples_per_s": fplan.samples / (f_ms * 1e-3),
-                               "step_form": "LDS-table (501 VALU + 29 LDS per slice)" if fc_clips * ch // 4 >= 2048
-                               else "register-table (660 VALU per slice)",
-                               "valu_issue": valu_issue(fc_clips * ch, fc_samples, f_ms, 501.0 if fc_clips * ch // 4 >= 2048 else 660.0),
+                               "step_form": "LDS-table (451 VALU + 26 LDS per slice)" if fc_clips * ch // 4 >= 8192
+                               else f"cheap-quotient register form ({K1_VALU_PER_SLICE:.0f} VALU per slice)",
+                               "valu_issue": valu_issue(fc_clips * ch, fc_samples, f_ms,
+                                                        451.0 if fc_clips * ch // 4 >= 8192 else K1_VALU_PER_SLICE),
                                "bit_exact_vs_oracle": bool(f_ok)}
         result["k1_extras"] = extras
         del fplan, fout

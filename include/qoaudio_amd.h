@@ -133,7 +133,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_FORCE_32BIT_STEP 2u   /* debug: never take the i16-packed fast path (same bytes, tests compare) */
 #define QOA_PLAN_NO_SPECULATION 4u     /* debug: packed path always with its penalty arithmetic (same bytes) */
 #define QOA_PLAN_LDS_TABLES 8u         /* debug: quantiser / dequantiser looked up in an LDS table in every launch (same bytes; */
-#define QOA_PLAN_NO_LDS_TABLES 128u    /*        default: only in launches with >= 2 wavefronts per SIMD) / in none */
+#define QOA_PLAN_NO_LDS_TABLES 128u    /*        default: only in launches with >= 8 wavefronts per SIMD) / in none */
 #define QOA_PLAN_EXACT_QUOTIENT 256u   /* debug: speculative steps always with the exact qoa_div fix-up (same bytes) */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
 #define QOA_PLAN_CPW_2 (2u << 4)

@@ -233,12 +233,13 @@ extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, 
                       ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) |
                       ((plan->flags & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u);
     for (auto *g : plan->groups) {
-        // The LDS-table step form spends fewer issue slots per slice but one LDS round trip per step: it pays once a launch
-        // gives every SIMD several wavefronts to cover that latency (>= 2 per SIMD on the 1024 SIMDs of the chip); below that
-        // the serial chain of a lone wavefront would wait for the table 20 times per slice.
+        // The LDS-table step form spends fewer issue slots per slice (505 vs 539 for the cheap-quotient register form) but has
+        // one LDS round trip per step on its serial chain: it only pays once a launch gives every SIMD about 8 wavefronts to
+        // cover that latency (measured, stereo clips x 32 frames: 4096 clips 72 vs 78 G samples/s, 8192: 81.5 vs 85.1,
+        // 16384: 91.9 vs 89.5 -- tools/k1lab/forms.py).
         unsigned lds = 0;
         if (plan->flags & QOA_PLAN_LDS_TABLES) lds = 16u;
-        else if (!(plan->flags & QOA_PLAN_NO_LDS_TABLES) && (g->n + g->cpw - 1) / g->cpw >= 2048u) lds = 16u;
+        else if (!(plan->flags & QOA_PLAN_NO_LDS_TABLES) && (g->n + g->cpw - 1) / g->cpw >= 8192u) lds = 16u;
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
                               kflags | lds, (unsigned long long *)plan->stats.p, (hipStream_t)stream),
                 QOA_ENCODE_IO_ERROR);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""K1 step forms side by side on config 3's signal (1024 stereo clips, FRAMES frames each): kernel time and the counters of
-qoa_encode_plan_stats4 per plan flag set.  Run on the GPU box:  python tools/k1lab/forms.py [frames]"""
+"""K1 step forms side by side on config 3's signal (CLIPS stereo clips, FRAMES frames each): kernel time and the counters of
+qoa_encode_plan_stats4 per plan flag set.  Run on the GPU box:  python tools/k1lab/forms.py [frames [clips]]"""
 import os
 import sys
 
@@ -11,14 +11,15 @@ from qoaudio_amd import batch, synth  # noqa: E402
 import qoaudio_amd as gpu  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-n_clips, ch = 1024, 2
+n_clips, ch = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 2
 samples = frames * 5120
 pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda")
 per = samples * ch
 enc = gpu.encoded_size(ch, samples)
 clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
 ref = None
-for name, fl in (("default (cheap quotient)", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT),
+for name, fl in (("default", 0), ("cheap quotient, no LDS tables", batch.PLAN_NO_LDS_TABLES),
+                 ("exact quotient, no LDS tables", batch.PLAN_EXACT_QUOTIENT | batch.PLAN_NO_LDS_TABLES),
                  ("no speculation", batch.PLAN_NO_SPECULATION), ("lds tables", batch.PLAN_LDS_TABLES)):
     plan = batch.EncodePlan(clips, fl)
     out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
@@ -36,5 +37,5 @@ for name, fl in (("default (cheap quotient)", 0), ("exact quotient", batch.PLAN_
         ref = out.clone()
     same = bool(torch.equal(ref, out))
     slices = n_clips * ch * frames * 256
-    print(f"{name:28s} {ms:8.3f} ms  {ms * 1e6 / (frames * 256):7.1f} ns/slice  declined/unpacked/spec-miss/cheap-declined "
+    print(f"{name:30s} {n_clips * samples * ch / ms / 1e6:7.2f} G samples/s {ms:8.3f} ms  {ms * 1e6 / (frames * 256):7.1f} ns/slice  declined/unpacked/spec-miss/cheap-declined "
           f"{s0} of {slices} slices  bytes equal: {same}")

@@ -87,6 +87,20 @@ KERNEL(k_sdwa_add, "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNU
 KERNEL(k_pk_ashr, "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %2, 15, %2 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %3, 15, %3 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %4, 15, %4 op_sel_hi:[0,1]\n")
 KERNEL(k_bfe_u, "v_bfe_u32 %0, %0, 3, 6\n v_bfe_u32 %2, %2, 3, 6\n v_bfe_u32 %3, %3, 3, 6\n v_bfe_u32 %4, %4, 3, 6\n")
 
+// r02: does an SDWA / packing consumer of a just-written VGPR cost more than a plain one?  (pairs are dependent both ways via %0)
+KERNEL(k_pair_plain, "v_ashrrev_i32 %0, 1, %0\n v_sub_u32 %0, %1, %0\n")
+KERNEL(k_pair_sdwa, "v_ashrrev_i32 %0, 1, %0\n v_sub_u32_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n")
+KERNEL(k_pair_sdwa_src, "v_ashrrev_i32 %0, 1, %0\n v_sub_u32_sdwa %0, sext(%0), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n")
+KERNEL(k_pair_sdwa_d2, "v_ashrrev_i32 %0, 1, %0\n v_add_u32 %2, %2, %1\n v_sub_u32_sdwa %0, sext(%0), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n")
+KERNEL(k_pair_sdwa_d3, "v_ashrrev_i32 %0, 1, %0\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_sub_u32_sdwa %0, sext(%0), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n")
+KERNEL(k_mad_mul, "v_mad_i32_i24 %0, %0, %1, %2\n v_mul_i32_i24 %0, %0, %1\n")
+KERNEL(k_mad_mul_sdwa, "v_mad_i32_i24 %0, %0, %1, %2\n v_mul_i32_i24_sdwa %0, sext(%0), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n")
+KERNEL(k_add_cvtpk, "v_add_u32 %0, %0, %1\n v_cvt_pk_i16_i32 %0, %1, %0\n")
+KERNEL(k_add_med3, "v_add_u32 %0, %0, %1\n v_med3_i32 %0, %0, %1, %2\n")
+KERNEL(k_or3_dep, "v_or3_b32 %0, %0, %1, %2\n")
+KERNEL(k_mul24_after_perm, "v_perm_b32 %0, %0, %1, %2\n v_mul_i32_i24 %0, %0, %1\n")
+KERNEL(k_xor_after_perm, "v_perm_b32 %0, %0, %1, %2\n v_xor_b32 %0, %0, %1\n")
+
 struct T { const char *name; void (*k)(unsigned long long *, int *, int); int per_body; };
 
 int main() {
@@ -112,6 +126,11 @@ int main() {
         {"v_max/min_i32 4-indep", k_maxmin, 4}, {"sub/and/lshl/or 4-indep", k_sub_and, 4}, {"v_alignbit 4-indep", k_alignbit, 4},
         {"v_lshl_add_u32 4-indep", k_lshl_add, 4}, {"v_add_u32_sdwa 4-indep", k_sdwa_add, 4}, {"v_pk_ashrrev_i16 4-indep", k_pk_ashr, 4},
         {"v_bfe_u32 4-indep", k_bfe_u, 4},
+        {"ashr -> sub (dep pair)", k_pair_plain, 2}, {"ashr -> sub_sdwa (src1 fresh)", k_pair_sdwa, 2},
+        {"ashr -> sub_sdwa (sel src fresh)", k_pair_sdwa_src, 2}, {"ashr, add, sub_sdwa (dist 2)", k_pair_sdwa_d2, 3},
+        {"ashr, add, add, sub_sdwa (d 3)", k_pair_sdwa_d3, 4},
+        {"mad24 -> mul24", k_mad_mul, 2}, {"mad24 -> mul24_sdwa", k_mad_mul_sdwa, 2}, {"add -> cvt_pk_i16_i32", k_add_cvtpk, 2},
+        {"add -> med3", k_add_med3, 2}, {"v_or3 dep", k_or3_dep, 1}, {"perm -> mul24", k_mul24_after_perm, 2}, {"perm -> xor", k_xor_after_perm, 2},
         {"v_sad_u32 dep", k_sad, 1}, {"v_xad_u32 dep", k_xad, 1}, {"v_mul_hi_i32_i24 dep", k_mul_u24_hi, 1},
     };
     printf("%-28s %12s %12s %12s   (cycles per instruction, s_memtime ticks)\n", "test", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
