@@ -12,10 +12,11 @@ The row, for one lane = one (frame, channel) chain (reference: decode_one_slice_
   (src/lib.rs:847-864); 10 x {6 bits -> entry, entry >> 4 = the two weight steps of :822};  range guard (below);
   20 x sample step:
       p      = dot2(w01, A) + dot2(w23, B)              the 4-tap prediction on i16 pairs, i32 wrapping sum (:799-805)
-      recon  = clamp((p >> 13) + deq, -32768, 32767)    (:310)
+      u      = (p >> 13) + deq                          unclamped reconstruction, alternating between two registers
       w     += sign(h) * (deq >> 4)                     2 x v_pk_mad_u16 with the (+-1, +-1) pairs (:822-826)
-      B'     = (h3, recon)                              v_alignbit_b32: the next history pair (:827)
-      image  <- recon                                   ds_write_b16 (stereo..) / ds_write_b32 of the pair (mono)
+      B'     = (clamp(u of the sample before), clamp(u))  ONE v_cvt_pk_i16_i32: the clamp of :310 and the next history
+                                                        pair of :827 (clamping the previous value again gives the same i16)
+      image  <- recon                                   ds_write_b16_d16_hi of B' (stereo) / ds_write_b32 of the pair (mono)
 Pair ring as in K1: B_n = (h[n-2], h[n-1]) lives in R[n % 4]; step n reads A = R[(n+2) % 4], B = R[n % 4], writes
 R[(n+1) % 4]; 20 % 4 == 0 brings every ring register back to its role, so %[pa], %[pm], %[pb] are plain in/out operands.
 
@@ -51,7 +52,8 @@ def ring(kind):
 def extraction():
     """10 lookups per row: entry j of the PAIR table [sf][code(2j) * 8 + code(2j+1)] = deq(2j) | deq(2j+1) << 16, then the
     two weight steps (deq >> 4, src/lib.rs:822) as one packed shift.  (One lookup per sample cost 2 VALU + 1 LDS read per
-    sample; this is 1.5 VALU + 0.5 reads.)"""
+    sample; this is 1.5 VALU + 0.5 reads.  8-byte entries that carry the weight steps too -- 1 VALU + 0.5 ds_read_b64 --
+    measured no faster for stereo and slower for mono: profiles/r02_k2lab_log.md, run 17.)"""
     L = []
     for j in range(10):
         p = 54 - 6 * j
@@ -79,18 +81,17 @@ def step(i, nch, row, ring_bytes):
     e, d = f"v{E0 + i // 2}", f"v{D0 + i // 2}"
     half = i % 2          # which half of the pair registers this sample uses
     bcast = "op_sel:[1,0,0]" if half else "op_sel:[0,0,0] op_sel_hi:[0,1,1]"   # that half into both lanes of src0
-    rc = f"v{RC0 + i % 2}"
+    u, uprev = f"v{RC0 + i % 2}", f"v{RC0 + (i + 1) % 2}"
     L = [
         f"v_dot2_i32_i16 v{P}, %[w01], {A}, 0",
         f"v_dot2_i32_i16 v{P}, %[w23], {B}, v{P}",
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",       # the inline 15 has no high half to select
         f"v_pk_mad_u16 %[w01], {d}, {SA}, %[w01] {bcast}",
         f"v_or_b32 {SB}, %[one2], {SB}",                           # (+-1, +-1) for B
-        f"v_ashrrev_i32 v{U}, 13, v{P}",
-        f"v_add_u32_sdwa v{U}, v{U}, sext({e}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{half}",
-        f"v_med3_i32 {rc}, v{U}, %[lo16], %[hi16]",
+        f"v_ashrrev_i32 {u}, 13, v{P}",
+        f"v_add_u32_sdwa {u}, {u}, sext({e}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{half}",
         f"v_pk_mad_u16 %[w23], {d}, {SB}, %[w23] {bcast}",
-        f"v_alignbit_b32 {Bn}, {rc}, {B}, 16",                    # (h3, recon)
+        f"v_cvt_pk_i16_i32 {Bn}, {uprev}, {u}",                   # (h3, recon), both clamped
     ]
     if nch == 1:
         if i & 1:  # consecutive samples are adjacent in a mono image: the new history pair IS the dword to store
@@ -98,7 +99,7 @@ def step(i, nch, row, ring_bytes):
             L.append(f"ds_write_b32 %[img], {Bn} offset:{off}")
     else:
         off = ((row * 20 + i) * nch * 2) % ring_bytes
-        L.append(f"ds_write_b16 %[img], {rc} offset:{off}")
+        L.append(f"ds_write_b16_d16_hi %[img], {Bn} offset:{off}")   # the new sample is the pair's high half
     return L
 
 
@@ -123,6 +124,7 @@ def row_text(nch, row, ring_bytes):
     ]
     # LDS ops retire in order: the table reads first, then one image write per sample (per second sample, mono)
     L += ["s_waitcnt lgkmcnt(5)"] + deltas(0, 5)      # entries 0..4 are in (the 5 youngest reads may still be out)
+    L += [f"v_ashrrev_i32 v{RC1}, 16, {ring('P')[0]}"]  # h3: sample 0's "reconstruction before"
     for i in range(20):
         if i == 8:
             # before sample 10: everything but the youngest image writes; the table reads are all older than those
@@ -167,7 +169,7 @@ def check_hazards(lines):
                 pop, pos = last[r]
                 if pop.startswith("v_dot2") and not (op.startswith("v_dot2") and r in ops[-1]):
                     assert n - pos >= 4, (l, pop, n - pos)
-                if pop.startswith("v_pk_"):
+                if pop.startswith("v_pk_") or pop.startswith("v_cvt_pk"):
                     assert n - pos >= 2, (l, pop, n - pos)
         for r in dst:
             last[r] = (op, n)
