@@ -260,8 +260,8 @@ def main():
         he = out[:2].cpu().numpy()
         ok = all(he[i].tobytes() == O.encode_all(hp[i].reshape(-1), ch, args.rate, samples) for i in range(2))
         result["bit_exact_vs_oracle"] = bool(ok)
-        declined, unpacked, misses, cheap_declined = plan.stats4()  # K1's fast paths: slices handed to a slower form, all launches
-        result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked, "speculation_misses": misses, "cheap_quotient_declines": cheap_declined,
+        declined, unpacked, misses, cheap_declined, marked = plan.counters()  # K1's fast paths: slices handed to a slower form, all launches
+        result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked, "speculation_misses": misses, "cheap_quotient_declines": cheap_declined, "cheap_quotient_marked_wave_slices": marked,
                                  "slices_total": (args.warmup + args.steps) * n_clips * ch * ((samples + 19) // 20)}
         if world > 1 and gathered is not None:
             # the gather itself: the first clip of the first and of the last rank's shard, as they arrived on rank 0,

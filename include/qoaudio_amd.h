@@ -159,10 +159,13 @@ int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_
  * The first two are 0 on ordinary audio.  Any pointer may be null. */
 int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices,
                           uint64_t *speculation_misses);
-/* The same three counters plus out[3] = slices the cheap-quotient step form declined (level from |quotient|, sign from the
- * residual: exact unless a scalefactor-0/1 candidate's quotient wraps to the opposite sign; such a slice is declined when
- * the winner cannot be proven against that candidate, and repeated with the exact qoa_div -- loud passages show these). */
-int qoa_encode_plan_stats4(qoa_encode_plan *plan, uint64_t out[4]);
+/* All counters, out[0..n): the three above, then
+ *   out[3] slices the cheap-quotient step form declined (level from |quotient|, sign from the residual: exact unless a
+ *          scalefactor-0/1 candidate's quotient wraps to the opposite sign; such a candidate is marked and must be beaten by
+ *          a bound derived from the slice's samples, else the slice is repeated with the exact qoa_div -- loud passages);
+ *   out[4] (wavefront, slice) pairs in which a candidate was marked at all (most are settled in place by the bound).
+ * Entries beyond the last counter read 0. */
+int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n);
 
 /* ---- batch encode on HOST-resident buffers: time-sliced pipeline ----
  * Semantically encode_all per clip (src/lib.rs:760-763) with h_pcm / h_out in host memory (pinned memory makes

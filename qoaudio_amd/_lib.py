@@ -17,7 +17,7 @@ SYMBOLS = [
     "qoa_encoded_size", "qoa_frame_size",
     "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
     "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_encode_all",
-    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_stats", "qoa_encode_plan_stats4",
+    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
     "qoa_encode_batch_host", "qoa_host_pipeline_create", "qoa_host_pipeline_free", "qoa_host_pipeline_encode",
     "qoa_host_pipeline_decode", "qoa_decode_batch_host",
     "qoa_decoder_new", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
@@ -107,7 +107,7 @@ def lib():
     L.qoa_encode_plan_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_run.argtypes = [vp, vp, vp, vp]
     L.qoa_encode_plan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.qoa_encode_plan_stats4.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.qoa_encode_plan_counters.argtypes = [vp, C.POINTER(C.c_uint64), sz]
     L.qoa_encode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]
     L.qoa_decode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]
     L.qoa_host_pipeline_create.argtypes = [C.POINTER(vp)]

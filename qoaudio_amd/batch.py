@@ -84,10 +84,11 @@ class EncodePlan:
             raise EncodeError(rc)
         return a.value, b.value, c.value
 
-    def stats4(self) -> Tuple[int, int, int, int]:
-        """stats() plus the slices the cheap-quotient step form declined (qoa_encode_plan_stats4)."""
-        out = (C.c_uint64 * 4)()
-        rc = _lib.lib().qoa_encode_plan_stats4(self._h, out)
+    def counters(self) -> Tuple[int, int, int, int, int]:
+        """stats() + (slices the cheap-quotient step form declined, wavefront-slices in which it marked a candidate)
+        (qoa_encode_plan_counters)."""
+        out = (C.c_uint64 * 5)()
+        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 5)
         if rc:
             raise EncodeError(rc)
         return tuple(int(v) for v in out)

@@ -134,11 +134,12 @@ struct EncGroup {
     DevBuf lms;
 };
 
+constexpr size_t kCounters = 5; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
 struct qoa_encode_plan {
     std::vector<EncGroup *> groups;
     uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;
     uint32_t flags = 0;
-    DevBuf stats; // 4 x u64, accumulated over every run of the plan
+    DevBuf stats; // kCounters x u64, accumulated over every run of the plan
     ~qoa_encode_plan() { for (auto *g : groups) delete g; }
 };
 
@@ -186,8 +187,8 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
     plan->samples = samples;
     plan->flags = flags;
     {
-        hipError_t e = plan->stats.reserve(4 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemset(plan->stats.p, 0, 4 * sizeof(uint64_t));
+        hipError_t e = plan->stats.reserve(kCounters * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemset(plan->stats.p, 0, kCounters * sizeof(uint64_t));
         if (e != hipSuccess) {
             delete plan;
             return fail_hip(e, "encode plan counters", QOA_ENCODE_IO_ERROR);
@@ -259,10 +260,12 @@ extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_s
     return QOA_OK;
 }
 
-extern "C" int qoa_encode_plan_stats4(qoa_encode_plan *plan, uint64_t out[4]) {
+extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n) {
     if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
+    uint64_t h[kCounters];
     HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR);
-    HIP_TRY(hipMemcpy(out, plan->stats.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(h, plan->stats.p, sizeof h, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    for (size_t i = 0; i < n; i++) out[i] = i < kCounters ? h[i] : 0;
     return QOA_OK;
 }
 

@@ -13,7 +13,8 @@ namespace qoa {
 //       bit4: speculative steps with the quantiser / dequantiser in an LDS table (fewer issue slots, one LDS round trip per
 //             step: for launches with several wavefronts per SIMD)
 //       bit5: no cheap-quotient speculative steps (run_block_spec<true>)
-// d_stats (may be null, 4 x u64; [3] += slices the cheap-quotient form declined, re-evaluated by the exact speculative form): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
+// d_stats (may be null, 5 x u64; [3] += slices the cheap-quotient form declined, re-evaluated by the exact speculative form,
+//                        [4] += (wavefront, slice) pairs in which the cheap-quotient form marked a candidate): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
 //                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible,
 //                        [2] += (chain, slice) pairs whose speculative evaluation was repeated by the full form
 hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out, const EncChain *d_chains,

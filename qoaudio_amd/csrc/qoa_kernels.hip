@@ -296,36 +296,44 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
 // it through the full form.  `pp` = byte distance between the two candidate-slot buffers.
 //
 // CHEAP selects QOA_BLOCK_CHEAP_ASM_TEXT, the same loop with the cheap quotient (tools/gen_slice_asm.py: cheap_quotient_note):
-// 25 / 28 instructions per step.  The quantiser's level is taken from |n| and its sign from the residual, which is what the
+// 22 / 25 instructions per step.  The quantiser's level is taken from |n| and its sign from the residual, which is what the
 // reference computes unless the wrapped quotient n and the residual have opposite signs (scalefactors 0 and 1 only); such a
 // candidate is marked, leaves the election, and the winner's rank must stay below the bound that comes with the slice's
 // samples (tile record dword 0: what a marked candidate provably costs) -- else the slice is declined like a speculation miss.
 template <bool CHEAP>
 __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
-                                                   int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk) {
+                                                   int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk,
+                                                   unsigned *marked_slices = nullptr) {
     register unsigned w01 asm("v84") = pk.w01;
     register unsigned w23 asm("v85") = pk.w23;
     register unsigned pa asm("v86") = pk.pa;
     register unsigned pb asm("v87") = pk.pb;
-    unsigned done;
-#define QOA_SPEC_OPERANDS                                                                                                  \
-                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)                                             \
-                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),                           \
-                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), \
-                   [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),          \
-                   [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),        \
-                   [mf0] "s"(0xf0), [pp] "s"(pp)                                                                            \
-                 : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
-                   "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92",    \
-                   "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",    \
-                   "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",     \
-                   "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+    unsigned done, marks;
+#define QOA_SPEC_CLOBBERS                                                                                                  \
+    "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",  \
+        "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",  \
+        "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",    \
+        "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", \
+        "v127"
+#define QOA_SPEC_INPUTS                                                                                                    \
+    [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 4),           \
+        [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), \
+        [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),       \
+        [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0xf0), [pp] "s"(pp)
     if constexpr (CHEAP) {
-        asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT QOA_SPEC_OPERANDS);
+        asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
+                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [marks] "=&s"(marks)
+                     : QOA_SPEC_INPUTS
+                     : QOA_SPEC_CLOBBERS);
+        if (marked_slices) *marked_slices = marks;
     } else {
-        asm volatile(QOA_BLOCK_SPEC_ASM_TEXT QOA_SPEC_OPERANDS);
+        asm volatile(QOA_BLOCK_SPEC_ASM_TEXT
+                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
+                     : QOA_SPEC_INPUTS
+                     : QOA_SPEC_CLOBBERS);
     }
-#undef QOA_SPEC_OPERANDS
+#undef QOA_SPEC_INPUTS
+#undef QOA_SPEC_CLOBBERS
     pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
     return done;
 }
@@ -645,9 +653,11 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                         while (j < kBlockSlices && proven) {
                             const bool cheap = allow_cheap && cheap_cooldown == 0;
                             if (cheap) {
+                                unsigned marked;
                                 j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
-                                                          dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk);
+                                                          dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
                                 j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+                                if (stats && marked && lane == 0) atomicAdd(&stats[4], (unsigned long long)marked);
                                 if (j == kBlockSlices) break;
                                 if (stats && sf == 0) atomicAdd(&stats[3], 1ull);
                                 if (blk - last_cheap_decline <= 1u) cheap_cooldown = kCheapCooldownBlocks + 1;

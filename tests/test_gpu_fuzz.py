@@ -144,3 +144,42 @@ def test_fuzz_decoder_iterator_on_damaged_streams(gpu, oracle, seed):
             if len(data) > 16:
                 data[int(r.integers(0, 16))] ^= 1 << int(r.integers(0, 8))
         _same_items(gpu, oracle, bytes(data))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_block_loop_from_hostile_states(gpu, oracle, seed):
+    """K1's block loop (cheap-quotient / exact speculative / full forms, chosen slice by slice on the device) entered from
+    random LMS states whose weights fit i16 -- up to the edge of the window the speculative forms accept, where predictions
+    reach +-250 k and the scalefactor-0 AND scalefactor-1 candidates' quotients wrap to the opposite sign -- on signals that
+    sit on the rails, alternate between them, or are ordinary: two blocks of 16 full slices per call, bytes and end state
+    against the oracle."""
+    from test_gpu_parity import _oracle_with_state
+    r = np.random.default_rng(seed)
+    channels, n = 2, 640
+    for trial in range(60 * SCALE):
+        amp = int(r.choice([3000, 9000, 12000, 12288, 14000, 15900, 16300]))
+        state = np.zeros((channels, 8), dtype=np.int32)
+        for c in range(channels):
+            w = r.integers(-amp, amp + 1, 4)
+            if r.random() < 0.5:   # all four products the same sign: the largest predictions the energy allows
+                w = np.abs(w) * np.sign(r.integers(0, 2) * 2 - 1)
+            h = r.integers(-32768, 32768, 4)
+            if r.random() < 0.5:
+                h = np.full(4, int(r.choice([-32768, 32767])))
+            state[c] = list(h) + list(w)
+        kind = str(r.choice(["rail", "flip", "white", "mix", "ramp"]))
+        if kind == "rail":
+            x = np.full(n * channels, int(r.choice([-32768, 32767])), dtype=np.int16)
+        elif kind == "flip":
+            x = rng_pcm(int(r.integers(1 << 30)), n * channels, "loud")
+        elif kind == "ramp":
+            x = np.clip(np.linspace(-40000, 40000, n * channels) * r.choice([-1, 1]), -32768, 32767).astype(np.int16)
+        else:
+            x = rng_pcm(int(r.integers(1 << 30)), n * channels, kind)
+        enc = gpu.QoaEncoder(gpu.QoaDesc(channels, 44100, n))
+        enc.set_lms_state(state)
+        fl, data = enc.encode_frame(x)
+        ref = _oracle_with_state(oracle, channels, 44100, n, state)
+        want, _ = ref.encode_frame(x)
+        assert fl == n and data == want, (trial, kind, state.tolist())
+        assert np.array_equal(enc.lms_state(), np.array([h + w for h, w in ref.lms_state()], dtype=np.int32))

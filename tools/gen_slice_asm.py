@@ -526,7 +526,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
     L = []
     L += [
         "s_mov_b32 s95, 0x10001",
-    ] + ([f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW:x}"] if spec else []) + ([f"v_mov_b32 {CH_BIG}, 0x7fffffff"] if cheap else []) + [
+    ] + ([f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW:x}"] if spec else []) + ([f"v_mov_b32 {CH_BIG}, 0x7fffffff", "s_mov_b32 %[marks], 0"] if cheap else []) + [
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an early exit restores
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
@@ -632,6 +632,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         "s_branch Lqoa_end_%=",
     ] + ([
         "Lqoa_marked_%=:",
+        "s_add_u32 %[marks], %[marks], 1",                   # (diagnostics: slices of this call with a marked candidate)
         f"v_cndmask_b32 {ELO}, {ELO}, {CH_BIG}, vcc",        # marked candidates leave the election ...
         f"v_mov_b32 {CH_BND}, {BOUND_IN}",                   # ... and the winner must beat what they provably cost
         "s_branch Lqoa_unmarked_%=",

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K1 step forms side by side on config 3's signal (CLIPS stereo clips, FRAMES frames each): kernel time and the counters of
-qoa_encode_plan_stats4 per plan flag set.  Run on the GPU box:  python tools/k1lab/forms.py [frames [clips]]"""
+qoa_encode_plan_counters per plan flag set.  Run on the GPU box:  python tools/k1lab/forms.py [frames [clips]]"""
 import os
 import sys
 
@@ -25,7 +25,7 @@ for name, fl in (("default", 0), ("cheap quotient, no LDS tables", batch.PLAN_NO
     out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
     plan.run(pcm.view(-1), out)
     torch.cuda.synchronize()
-    s0 = plan.stats4()
+    s0 = plan.counters()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
@@ -37,5 +37,5 @@ for name, fl in (("default", 0), ("cheap quotient, no LDS tables", batch.PLAN_NO
         ref = out.clone()
     same = bool(torch.equal(ref, out))
     slices = n_clips * ch * frames * 256
-    print(f"{name:30s} {n_clips * samples * ch / ms / 1e6:7.2f} G samples/s {ms:8.3f} ms  {ms * 1e6 / (frames * 256):7.1f} ns/slice  declined/unpacked/spec-miss/cheap-declined "
+    print(f"{name:30s} {n_clips * samples * ch / ms / 1e6:7.2f} G samples/s {ms:8.3f} ms  {ms * 1e6 / (frames * 256):7.1f} ns/slice  declined/unpacked/spec-miss/cheap-declined/marked "
           f"{s0} of {slices} slices  bytes equal: {same}")
