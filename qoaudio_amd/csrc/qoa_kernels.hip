@@ -441,12 +441,14 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
 //
 // Memory schedule.  All global-memory traffic of a chain happens once per BLOCK of 16 slices
 // (320 sample-times), in straight-line code at the block top: lane j of the chain's 16-lane row
-// loads the 20 samples of slice 16*(blk+1)+j for the NEXT block (20 x global_load_sshort, addresses
-// clamped instead of branched), parks the 20 samples it loaded one block earlier in a wave-private
-// LDS tile [chain][slice j][20] (5 x ds_write_b128), and stores the 8-byte slice it kept for row
-// 16*(blk-1)+j of the PREVIOUS block.  Inside a block there is no vector-memory instruction at all,
-// so no s_waitcnt vmcnt can land on the serial slice step; the 16 candidate lanes of a chain fetch
-// a slice's 20 samples with 5 broadcast ds_read_b128.  A frame is exactly 16 blocks, so frame
+// loads the 20 samples of slice 16*(blk+1)+j for the NEXT block (20 x 16-bit loads into 10 pair registers,
+// addresses clamped instead of branched), parks the 10 pairs it loaded one block earlier -- behind the
+// slice's marked-candidate bound, a 48-byte record -- in a wave-private LDS tile [chain][slice j]
+// (3 x ds_write_b128), and stores the 8-byte slice it kept for row 16*(blk-1)+j of the PREVIOUS block.
+// Inside a block there is no vector-memory instruction at all, so no s_waitcnt vmcnt can land on the
+// serial slice step; the 16 candidate lanes of a chain fetch a slice's record with 3 broadcast
+// ds_read_b128 (the speculative forms work on the pairs as they are, the others widen them in place).
+// A frame is exactly 16 blocks, so frame
 // headers / LMS dumps are written at block tops too.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlockSlices = 16;

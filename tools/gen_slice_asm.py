@@ -10,7 +10,12 @@ every ring register again holds the element it started with) and puts every wait
   QOA_SLICE_PK_ASM_TEXT    20 x pk_step(): 35 instructions on i16-packed weights / history, one slice.
   QOA_BLOCK_PK_ASM_TEXT    pk_block(): a loop over up to 16 slices of pk_step() incl. winner election and LDS exchange;
                            the straight-line body is ordered by schedule().
-  QOA_BLOCK_SPEC_ASM_TEXT  pk_block(spec=True): the same loop on speculative steps (30 / 33 instructions).
+  QOA_BLOCK_SPEC_ASM_TEXT  pk_block(spec=True): the same loop on speculative steps (26 / 29 instructions; i16 sample pairs,
+                           saturating 32-bit rank formed two steps at a time, v_cvt_pk_i16_i32 for the history pair).
+  QOA_BLOCK_SPEC_LDSQ_ASM_TEXT  ... with the quantiser / dequantiser in an LDS table (pk_step_ldsq).
+  QOA_BLOCK_CHEAP_ASM_TEXT pk_block(spec=True, cheap=True): speculative steps with the cheap quotient (22 / 25 instructions,
+                           cheap_quotient_note()).
+All forms read a slice's samples from its 48-byte LDS tile record (sample_reads()).
 """
 import os
 
@@ -667,14 +672,14 @@ def render(verbose=False):
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
            "// QOA_BLOCK_PK_ASM_TEXT: a loop over consecutive full slices on the packed path incl. winner election and\n"
            "//   state exchange; fixed registers v67-v127, state in v[84:87].\n"
-           "// QOA_BLOCK_SPEC_ASM_TEXT: the same loop with speculative steps (30/33 instructions, no penalty arithmetic) and\n"
+           "// QOA_BLOCK_SPEC_ASM_TEXT: the same loop with speculative steps (26/29 instructions, no penalty arithmetic) and\n"
            "//   the two energy tests that prove a slice's result; fixed registers v64-v127.\n"
            + emit("QOA_SLICE_ASM_TEXT", lines) + "\n" + emit("QOA_SLICE_PK_ASM_TEXT", pk) + "\n"
            + emit("QOA_BLOCK_PK_ASM_TEXT", blk) + "\n" + emit("QOA_BLOCK_SPEC_ASM_TEXT", blk_spec) + "\n"
-           + "// QOA_BLOCK_SPEC_LDSQ_ASM_TEXT: the speculative loop with the quantiser + dequantiser in an LDS table (22/25\n"
+           + "// QOA_BLOCK_SPEC_LDSQ_ASM_TEXT: the speculative loop with the quantiser + dequantiser in an LDS table (21/24\n"
            + "//   VALU + 1 LDS read per step): for launches that give every SIMD several wavefronts.\n"
            + emit("QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", blk_ldsq) + "\n"
-           + "// QOA_BLOCK_CHEAP_ASM_TEXT: the speculative loop with the cheap quotient (25/28 VALU per step; level from |n|, sign\n"
+           + "// QOA_BLOCK_CHEAP_ASM_TEXT: the speculative loop with the cheap quotient (22/25 VALU per step; level from |n|, sign\n"
            + "//   from the residual, candidates whose quotient wrapped to the opposite sign are marked and proven losers).\n"
            + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap))
     return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap))
