@@ -88,18 +88,22 @@ __device__ __forceinline__ bool fits_i16(int v) { return (unsigned)(v + 32768) <
 // residual (src/lib.rs:309), high half = that value >> 4, the weight step of src/lib.rs:822 -- so the sample costs no
 // code-to-magnitude arithmetic at all, and the 20 lookups of a row are issued ahead of its serial chain.
 // B_i = (h[i-2], h[i-1]); the three live history pairs rotate by name in the unrolled caller.
-__device__ __forceinline__ int decode_step_pk(unsigned &w01, unsigned &w23, unsigned A, unsigned B, unsigned SA, unsigned SB,
-                                              unsigned &Bn, unsigned entry) {
+// `before` = the unclamped reconstruction of the sample before (h3 at a row's first sample), updated to this one's: the next
+// history pair (h3, recon) is ONE v_cvt_pk_i16_i32 of the two -- it clamps both (:310; clamping the older value again gives
+// the same i16) and packs them (:827).  Returns the pair; the new sample is its high half.
+__device__ __forceinline__ unsigned decode_step_pk(unsigned &w01, unsigned &w23, unsigned A, unsigned B, unsigned SA, unsigned SB,
+                                                   int &before, unsigned entry) {
     int p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w01), __builtin_bit_cast(pk_i16, A), 0, false);
     p = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, w23), __builtin_bit_cast(pk_i16, B), p, false);
     const int deq = (int)(short)(entry & 0xffffu);
-    const int recon = med3((p >> 13) + deq, -32768, 32767);
+    const int u = (p >> 13) + deq;
     const short delta = (short)(entry >> 16);
     const pk_i16 d2 = {delta, delta};
     w01 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SA) * d2 + __builtin_bit_cast(pk_i16, w01)));
     w23 = __builtin_bit_cast(unsigned, (pk_i16)(__builtin_bit_cast(pk_i16, SB) * d2 + __builtin_bit_cast(pk_i16, w23)));
-    Bn = __builtin_amdgcn_alignbit((unsigned)recon, B, 16); // (h3, recon)
-    return recon;
+    const unsigned Bn = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(before, u));
+    before = u;
+    return Bn;
 }
 
 // LDS dequant table for the packed rows: [sf][code] = (dequant & 0xffff) | ((dequant >> 4) << 16)
@@ -336,12 +340,13 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
             if (__builtin_amdgcn_ballot_w64(!row_ok) == 0ull) {
                 // pair ring as in K1: B_i = (h[i-2], h[i-1]) lives in P[i % 4]; step i reads P[(i+2)%4] and P[i%4]
                 unsigned P[4] = {pk.pb, 0u, pk.pa, pk.pm}, S[4] = {pk.sb, 0u, pk.sa, pk.sm};
+                int before = (int)pk.pb >> 16; // h3
 #pragma unroll
                 for (int i = 0; i < 20; i++) {
-                    const int rec = decode_step_pk(pk.w01, pk.w23, P[(i + 2) % 4], P[i % 4], S[(i + 2) % 4], S[i % 4],
-                                                   P[(i + 1) % 4], entry[i]);
+                    P[(i + 1) % 4] = decode_step_pk(pk.w01, pk.w23, P[(i + 2) % 4], P[i % 4], S[(i + 2) % 4], S[i % 4], before,
+                                                    entry[i]);
                     S[(i + 1) % 4] = pk_signs(P[(i + 1) % 4]);
-                    *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)rec;
+                    *(int16_t *)(img + my_img + (r * 20 + i) * (NCH * 2)) = (int16_t)(P[(i + 1) % 4] >> 16);
                 }
                 pk.pa = P[2]; pk.pm = P[3]; pk.pb = P[0]; // 20 % 4 == 0: the ring is back in place
                 pk.sa = S[2]; pk.sm = S[3]; pk.sb = S[0];
