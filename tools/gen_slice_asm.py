@@ -577,11 +577,17 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
     if verbose:
         print(f"block body{' (speculative)' if spec else ''}: {len(body)} instructions after scheduling, "
               f"{b2b} consumers directly behind their producer")
+    tail = []
+    if cheap and body[-2] == "s_nop 0" and body[-1].startswith("v_dot2") and body[-3].startswith("v_pk_sub"):
+        # the first exit branch serves as the wait state between the last error pair's v_pk_sub and its v_dot2 (a declined
+        # slice does not need the rank); the v_dot2 still has v_cmp, branch, v_xor, v_lshl_or in front of the first DPP read
+        tail = [body[-1]]
+        body = body[:-2]
     L += body
     L += ([] if spec and not ldsq else
           [f"v_cmp_ge_i32 vcc, {QM}, %[limq]" if spec else f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]"]) + [
         "s_cbranch_vccnz Lqoa_declined_%=",
-    ] + ([
+    ] + tail + ([
         f"v_cmp_gt_i32 vcc, 0, {CH_W}",                      # any candidate marked (cheap_quotient_note)?
         "s_cbranch_vccnz Lqoa_marked_%=",
         "Lqoa_unmarked_%=:",
