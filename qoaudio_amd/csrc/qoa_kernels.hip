@@ -287,13 +287,15 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
     return done;
 }
 
-// The speculative form of run_block_pk (QOA_BLOCK_SPEC_ASM_TEXT): steps without any penalty arithmetic (30 instructions,
-// 33 at the five steps that sample the weight energy), proven after each slice by two tests on the sampled maximum --
+// The speculative form of run_block_pk (QOA_BLOCK_SPEC_ASM_TEXT): steps without any penalty arithmetic (26 instructions,
+// 29 at the five steps that sample the weight energy), proven after each slice by two tests on the sampled maximum --
 // limq: every candidate stayed inside the i16 window (so all 64 ranks are exact err^2 sums); winq: the WINNER's penalty
 // was zero at every step, hence its rank is its true rank while every other candidate's true rank is >= its computed
 // one, and the reference's winner is this winner.  Margins for the three unsampled steps are folded into limq / winq
-// (spec_limits).  A slice that fails either test ends the call (done < n) with its entry state restored; the caller runs
-// it through the full form.  `pp` = byte distance between the two candidate-slot buffers.
+// (spec_limits).  The rank is a saturating 32-bit sum (tools/gen_slice_asm.py: spec_rank_pair): a third test demands
+// that the winner's is below 32767^2, where it is provably the true rank.  A slice that fails a test ends the call
+// (done < n) with its entry state restored; the caller runs it through the full form.  `pp` = byte distance between the
+// two candidate-slot buffers.
 //
 // CHEAP selects QOA_BLOCK_CHEAP_ASM_TEXT, the same loop with the cheap quotient (tools/gen_slice_asm.py: cheap_quotient_note):
 // 22 / 25 instructions per step.  The quantiser's level is taken from |n| and its sign from the residual, which is what the
