@@ -630,6 +630,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {cand}",           # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
+    ] + ["s_nop 0"] * int(os.environ.get("QOA_GEN_NOPS_BEHIND_STATE_READ", "0")) + [   # (experiment: how long is the read exposed?)
         f"v_cmp_eq_u32 vcc, {ADDR}, {cand}",
         f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
     ] + ([f"v_cndmask_b32 {THR}, %[limq], %[winq], vcc"] if spec else []) + [   # non-winners: the test they already passed
