@@ -263,7 +263,7 @@ __device__ __forceinline__ void run_slice_pk(unsigned tile_addr, int sf, const S
 
 // `n` consecutive full slices of a block on the packed path in ONE statement (QOA_BLOCK_PK_ASM_TEXT): candidate steps,
 // winner election, exchange of the winner's state through the chain's 16 LDS slots (`cand` = this lane's slot, slots
-// are 16 bytes, a row's 16 slots are 256-byte aligned) and staging of the winner's slice words at `outb + 8 * i`
+// are 32 bytes apart, a row's 16 slots are 512-byte aligned) and staging of the winner's slice words at `outb + 8 * i`
 // (the others write to `dummy`).  Returns how many slices were completed; fewer than n means slice number `done`
 // failed the kPkPenLimit test -- `pk` then holds that slice's entry state and the caller takes the 32-bit path.
 __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned cand, unsigned outb, unsigned dummy, int sf,
@@ -276,9 +276,9 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
     asm volatile(QOA_BLOCK_PK_ASM_TEXT
                  : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
-                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
+                   [sf4] "v"((unsigned)sf << 5), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
                    [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
-                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0xf0)
+                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0x1e0)
                  : "vcc", "scc", "memory", "s95", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
                    "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
                    "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
@@ -318,10 +318,10 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
         "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", \
         "v127"
 #define QOA_SPEC_INPUTS                                                                                                    \
-    [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 4),           \
+    [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),           \
         [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), \
         [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),       \
-        [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0xf0), [pp] "s"(pp)
+        [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
     if constexpr (CHEAP) {
         asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
                      : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [marks] "=&s"(marks)
@@ -355,10 +355,10 @@ __device__ __forceinline__ unsigned run_block_spec_ldsq(unsigned tile_addr, unsi
     asm volatile(QOA_BLOCK_SPEC_LDSQ_ASM_TEXT
                  : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
-                   [sf4] "v"((unsigned)sf << 4), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [qtab] "v"(qtab),
+                   [sf4] "v"((unsigned)sf << 5), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [qtab] "v"(qtab),
                    [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
                    [rnd] "s"(1 << 15), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n),
-                   [mf0] "s"(0xf0), [pp] "s"(pp)
+                   [mf0] "s"(0x1e0), [pp] "s"(pp)
                  : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
                    "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
                    "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
@@ -520,10 +520,12 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // candidate end states of the slice in flight; two buffers: the speculative loop alternates between them so that
     // a slice's entry state (the previous winner's slot) survives until the slice is known to be final.  It switches
     // buffers with one v_xor of the slot address, so the pair must be aligned to its own size (and a row's 16 slots to
-    // 256 bytes for the winner-address trick).
-    constexpr unsigned kCandBufBytes = 4u * CPW * 16u * sizeof(uint4);
+    // 512 bytes for the winner-address trick).
+    // A slot is 32 bytes: the packed state (weights, the history pairs (h0,h1) and (h2,h3)) and, in the speculative forms,
+    // what the next slice's first steps need besides ((h1,h2), the unclamped last reconstruction, two sign pairs).
+    constexpr unsigned kCandBufBytes = 4u * CPW * 16u * 2u * sizeof(uint4);
     static_assert((kCandBufBytes & (kCandBufBytes - 1)) == 0, "buffer size must be a power of two");
-    __shared__ __attribute__((aligned(2 * kCandBufBytes))) uint4 s_cand[2][4][CPW][16];
+    __shared__ __attribute__((aligned(2 * kCandBufBytes))) uint4 s_cand[2][4][CPW][16][2];
     // [0,16): the block's winning slices, [16,32): per-lane dummies; 48 entries = 384 B per chain so that the two
     // chains a 64-lane ds_write_b64 serves per pass fall on disjoint banks
     __shared__ __attribute__((aligned(16))) uint2 s_out[4][CPW][48];
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     int *tile = s_smp + (wave_in_block * CPW + grp) * kTileInts;
     uint2 *out_tile = s_out[wave_in_block][grp];
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[0][wave_in_block][grp][sf];
+    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[0][wave_in_block][grp][sf][0];
     const unsigned outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
 
     const EncChain ch = chains[chain_id];

@@ -115,7 +115,7 @@ PK_FIXED = dict(w01="v84", w23="v85", pen="v88", e="v[82:83]", acca="v89", accb=
 
 
 def pk_step(i, N=PK_OPERANDS, spec=False):
-    R, S, RC = N["R"], PK_S, PK_RC
+    R, S, RC = N["R"], PK_S, N.get("RC", PK_RC)
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
     smp = f"v{SMP0 + i}"
@@ -266,6 +266,11 @@ def spec_aerr0(N, E, X):
                                             f"v_max_i32 {N['aerr0']}, {X}, {N['aerr0']}")]
 
 
+# Speculative block loops: the part of a candidate's end state that the next slice's first steps would otherwise re-derive
+# from the history pairs -- B_19 = (h17, h18), the unclamped last reconstruction (-> h19), the sign pairs of B_18 and B_19 --
+# sits in v[92:95] and travels through the second half of the candidate's 32-byte LDS slot (pk_block).
+SPEC_REGS = dict(R=["v87", "v124", "v86", "v92"], RC=["v102", "v93"])
+SLOT2 = "v[92:95]"
 ELO_REG = "v82"   # the block loops' rank register (PK_FIXED e = v[82:83]; the speculative forms use the low dword only)
 
 
@@ -279,7 +284,7 @@ def pk_step_ldsq(i, N, deferred=None):
     read's wait is a fence, and with other wavefronts filling the slots dependent issue costs nothing).
     Returns (lines, acc_line): the slice-word accumulate of this step is handed to the NEXT step (`deferred`), which issues
     it in the wait states behind its v_dot2 pair -- at odd steps nothing else is left to fill them."""
-    R, S, RC = N["R"], PK_S, PK_RC
+    R, S, RC = N["R"], PK_S, N.get("RC", PK_RC)
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
     smp = f"v{SMP0 + i}"
@@ -334,7 +339,7 @@ def pk_zero(N):
 
 def pk_prologue(N, zero=True, spec=False):
     R, S = N["R"], PK_S
-    return ([f"v_ashrrev_i32 {PK_RC[1]}, 16, {R[0]}"] if spec else []) + [   # h3: step 0's "previous reconstruction"
+    return ([f"v_ashrrev_i32 {N.get('RC', PK_RC)[1]}, 16, {R[0]}"] if spec else []) + [   # h3: step 0's "previous reconstruction"
         f"v_alignbit_b32 {R[3]}, {R[0]}, {R[2]}, 16",        # B_(-1) = (h1, h2)
         f"v_pk_ashrrev_i16 {S[2]}, 15, {R[2]} op_sel_hi:[0,1]",
         f"v_pk_ashrrev_i16 {S[3]}, 15, {R[3]} op_sel_hi:[0,1]",
@@ -503,8 +508,9 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
     Winner election = two 16-lane DPP min reductions (keys: rank >> 5, then rank[7:0] : |err0| : sf << 4).  The two
     wait states a DPP read needs after a VALU write of its source are filled with the slice-word packing, the loop
     counter and the NEXT slice's five sample reads, so the reads' latency is off the serial chain too.
-    Exchange: every candidate parks its end state in its own 16-byte LDS slot before the election; afterwards all 16
-    lanes read the winner's slot ((key2 & 0xf0) selects it: slots are 16 bytes, rows 256-byte aligned).
+    Exchange: every candidate parks its end state in its own LDS slot before the election; afterwards all 16 lanes read
+    the winner's slot ((key2 & 0x1e0) selects it: slots are 32 bytes apart, rows 512-byte aligned).  The full form uses
+    the first 16 bytes (weights + the two history pairs of the state); the speculative forms also SLOT2.
 
     spec=True is the speculative form: the steps carry no penalty arithmetic (pk_step); instead every candidate's
     weight energy minus 0x8ff << 18, sampled at steps 0, 4, .. 16, is kept as a running maximum QM and tested twice:
@@ -514,7 +520,8 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
                                          other candidate's true rank is at least its computed one: same winner).
     The second test comes after the election, when this slice's candidates already sit in the LDS slots; the slots are
     therefore double-buffered (%[pp] = byte distance) so that the entry state is still there for a late exit."""
-    N = PK_FIXED
+    N = dict(PK_FIXED, **SPEC_REGS) if spec else PK_FIXED
+    assert not spec or (N["R"][3], N["RC"][1], PK_S[2], PK_S[3]) == ("v92", "v93", "v94", "v95")   # = SLOT2
     K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"   # K1/M/K2 share the dot registers (long dead by now)
     TCUR, OCUR = "v78", "v77"
     SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
@@ -536,13 +543,15 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
         f"v_mov_b32 {prev}, %[cand]",
-    ] + ([f"v_mov_b32 {CANDC}, %[cand]"] if spec else []) + sample_reads("%[tile]") + zero + [
+    ] + ([f"v_mov_b32 {CANDC}, %[cand]"] if spec else []) + sample_reads("%[tile]") + zero + (
+        pk_prologue(N, zero=False, spec=True) if spec else []) + [   # speculative loops: once per call; then SLOT2 carries it
         "s_mov_b32 %[done], 0",
         "s_waitcnt lgkmcnt(0)",
         "Lqoa_top_%=:",
-        "s_waitcnt lgkmcnt(1)",                              # the winner's state (only a slice-word store may trail)
+        # the winner's state; a slice-word store may trail, and in the speculative loops SLOT2's read (waited for below)
+        f"s_waitcnt lgkmcnt({2 if spec else 1})",
     ]
-    body = pk_prologue(N, zero=False, spec=spec)             # rank and penalty sums are cleared in the election's gaps
+    body = [] if spec else pk_prologue(N, zero=False)        # rank and penalty sums are cleared in the election's gaps
     if ldsq:
         N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
     elif spec:
@@ -577,6 +586,9 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
     if verbose:
         print(f"block body{' (speculative)' if spec else ''}: {len(body)} instructions after scheduling, "
               f"{b2b} consumers directly behind their producer")
+    if spec:   # SLOT2 is first needed near the end of step 0: wait for it there, not at the loop top
+        first = min(k for k, l in enumerate(body) if l.startswith("v_") and set(_parse(l)[2]) & {"v92", "v93", "v94", "v95"})
+        body.insert(first, "s_waitcnt lgkmcnt(1)")
     tail = []
     if cheap and body[-2] == "s_nop 0" and body[-1].startswith("v_dot2") and body[-3].startswith("v_pk_sub"):
         # the first exit branch serves as the wait state between the last error pair's v_pk_sub and its v_dot2 (a declined
@@ -593,14 +605,15 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         "Lqoa_unmarked_%=:",
     ] if cheap else []) + ([f"v_xor_b32 {CANDC}, %[pp], {CANDC}"] if spec else []) + ([   # the other slot buffer: the entry state stays put
         # keys of the full form: rank < 2^37 -> rank >> 5, then rank[7:0] : |err0| : sf << 4
+        # (slots are 32 bytes apart: %[sf4] = sf << 5, %[mf0] = 0x1e0; the second key keeps rank[6:0] : |err0| : sf << 5)
         f"ds_write_b128 {cand}, v[84:87]",
         f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
-        f"v_lshlrev_b32 {K2}, 24, {ELO}",
-        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, {K2}",
+        f"v_lshlrev_b32 {K2}, 25, {ELO}",
+        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
         f"v_or_b32 {K2}, %[sf4], {K2}",
     ] if not spec else [
-        # speculative form: the saturating rank is one dword; second key |err0| : sf << 4
-        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 8, %[sf4]",
+        # speculative form: the saturating rank is one dword; second key |err0| : sf << 5
+        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]",
     ]) + [
         f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
@@ -618,7 +631,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         f"v_add_u32 {OCUR}, 8, {OCUR}",
         dpp(K2, 8),
         f"ds_write_b128 {cand}, v[84:87]" if spec else "s_nop 0",
-        "s_nop 0",
+        f"ds_write_b128 {cand}, {SLOT2} offset:16" if spec else "s_nop 0",
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
         "s_cmp_lt_u32 %[done], %[n]",
@@ -630,7 +643,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {cand}",           # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
-    ] + ["s_nop 0"] * int(os.environ.get("QOA_GEN_NOPS_BEHIND_STATE_READ", "0")) + [   # (experiment: how long is the read exposed?)
+    ] + ([f"ds_read_b128 {SLOT2}, {ADDR} offset:16"] if spec else []) + ["s_nop 0"] * int(os.environ.get("QOA_GEN_NOPS_BEHIND_STATE_READ", "0")) + [   # (experiment: how long is the read exposed?)
         f"v_cmp_eq_u32 vcc, {ADDR}, {cand}",
         f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
     ] + ([f"v_cndmask_b32 {THR}, %[limq], %[winq], vcc"] if spec else []) + [   # non-winners: the test they already passed
