@@ -59,13 +59,13 @@ def pmc_traffic(kernel: str, clips: int, channels: int, frames: int):
         return None, "traffic_stale: kernel sources changed since the PMC profile " + str(d.get("source"))
     return d[kernel]["traffic_bytes_per_launch"], None
 
-K1_VALU_PER_SLICE = 534.0  # PMC: SQ_INSTS_VALU / (wavefronts x slices) on config 3, profiles/r02_pmc_summary.txt
+K1_VALU_PER_SLICE = 528.0  # PMC: SQ_INSTS_VALU / (wavefronts x slices) on config 3, profiles/r02_pmc_summary.txt
 
 
 def valu_issue(n_chains: int, samples: int, kernel_ms: float, per_slice: float = K1_VALU_PER_SLICE):
     """Secondary roofline for K1: VALU wave-instructions issued per second against the chip's issue peak.
-    Instruction count per slice is PMC-measured (SQ_INSTS_VALU / slices / waves): 534 for the cheap-quotient register form
-    (config 3, profiles/r02_pmc_summary.txt; 523 in the block loop, the rest are the block tops; 660 at the start of round
+    Instruction count per slice is PMC-measured (SQ_INSTS_VALU / slices / waves): 528 for the cheap-quotient register form
+    (config 3, profiles/r02_pmc_summary.txt; 517 in the block loop, the rest are the block tops; 660 at the start of round
     2); the LDS-table form that launches with >= 8 wavefronts per SIMD use has 451 (+ 26 LDS) in its loop.  A SIMD issues at
     most one instruction per 4 cycles whatever the wavefront count (profiles/r02_ubench_gfx950_issue_classes.txt)."""
     waves = (n_chains + 3) // 4
@@ -243,7 +243,7 @@ def main():
                      "traffic": enc_traffic, "kernel": "qoa_encode_kernel",
                      "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "integer-VALU-issue bound (serial LMS chain per channel), see DESIGN.md",
-                     # the bound that actually governs K1 (profiles/r02_pmc_summary.txt): 534 VALU wave-instructions
+                     # the bound that actually governs K1 (profiles/r02_pmc_summary.txt): 528 VALU wave-instructions
                      # per slice per wavefront, one per 4 cycles per SIMD at 2.4 GHz on 1024 SIMDs
                      "valu_issue": valu_issue(n_clips * ch, samples, k_avg_ms)},
     }
