@@ -258,6 +258,46 @@ def test_kernel_quantiser_closed_form_is_exact_for_every_residual():
         assert np.array_equal(deq_ref, deq_k), sf
 
 
+def test_cheap_quotient_form_is_exact_wherever_it_does_not_mark():
+    """K1's cheap-quotient step (tools/gen_slice_asm.py: cheap_quotient_note) for EVERY residual the packed forms can see
+    (|residual| <= 2^18 + 32768: i16 weights and history) and all 16 scalefactors: a1 = sgn'(v), q = n * a1 with n taken as
+    the signed high word of the 32-bit product, level = min(q, 7) & -10, code = level - (v >> 31), dequantised = mag * a1.
+    Wherever q >= 0 code and dequantised value equal the reference's (src/lib.rs:613-617, :569-572); q < 0 (the lane is
+    marked) happens only at scalefactors 0 and 1, only with |v| >= 32768, and -- the premise of the marked-candidate
+    bound -- the reference's own dequantised value is then at most 49 in magnitude."""
+    res = np.arange(-(2 ** 18) - 32768, 2 ** 18 + 32768 + 1, dtype=np.int64)
+    sext24 = lambda v: ((v + 2 ** 23) % 2 ** 24) - 2 ** 23
+    sext16 = lambda v: ((v + 2 ** 15) % 2 ** 16) - 2 ** 15
+    wrap32 = lambda v: ((v + 2 ** 31) % 2 ** 32) - 2 ** 31
+    marked_total = 0
+    for sf in range(16):
+        n = wrap32(wrap32(res * RECIP[sf]) + 32768) >> 16
+        scaled = n + np.sign(res) - np.sign(n)
+        code_ref = QUANT_TAB[np.clip(scaled, -8, 8) + 8]
+        deq_ref = DEQUANT[sf][code_ref]
+        # the kernel's instructions
+        u = wrap32(sext24(res) * sext24(RECIP[sf]) + 32768)            # v_mad_i32_i24
+        sn = res >> 31                                                  # v_ashrrev_i32 31
+        a1 = sn | 1                                                     # v_or_b32 1
+        q = wrap32(sext24(sext16(u >> 16)) * sext24(a1))                # v_mul_i32_i24_sdwa, src0 = sext(WORD_1)
+        t = np.minimum(q, 7)                                            # v_min_i32 (kept for the marking OR)
+        level = t & -10                                                 # v_and_b32 -10
+        ok = q >= 0
+        mag = DEQUANT[sf][np.where(ok, level, 0)]
+        deq_k = wrap32(sext24(mag) * sext24(a1))                        # v_mul_i32_i24
+        code_k = level - sn
+        assert np.array_equal(code_ref[ok], code_k[ok]) and np.array_equal(deq_ref[ok], deq_k[ok]), sf
+        marked = ~ok
+        assert np.array_equal(t[marked] < 0, np.ones(marked.sum(), dtype=bool))  # the OR of the steps' t sees it
+        if sf >= 2:
+            assert not marked.any(), sf
+        else:
+            assert marked.any() and np.abs(res[marked]).min() >= (32768 if sf == 0 else 229355), sf
+            assert np.abs(deq_ref[marked]).max() <= 49
+        marked_total += int(marked.sum())
+    assert marked_total > 0
+
+
 def test_mul24_equals_wrapping_mul_inside_the_guard():
     """v_mul_i32_i24 returns the low 32 bits of sext24(a)*sext24(b): equal to the wrapping i32 product for
     every operand pair the fast path can produce (|w| < 2^23 at all 20 steps, |h| <= 2^15)."""

@@ -304,8 +304,8 @@ def pk_step_ldsq(i, N, deferred=None):
         f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}" if check else None,
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",
         slot_a,
+        deferred,                                           # (also keeps the packed shift's result one slot away from the v_or)
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",
-        deferred,
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
         spec_residual(i, T, PR),
         slot_b,
