@@ -5,7 +5,7 @@ for uniform full frames, qoa_decode.hip) as ONE inline-asm statement per (channe
 Why asm: K2u is bound by VALU issue (profiles/r02_*: the VALU is busy ~80 % of the kernel at the ~1.9 GHz the chip runs
 this memory-heavy kernel at), so its cost is the instruction count of the serial sample step.  hipcc's code spends
 14.4 VALU per sample (an accumulator-zeroing move per sample for v_dot2c, state shuffling around every row, a
-10-instruction range guard per row); this text spends 10 per sample + 1.5 for the table lookup + ~8 per row.
+10-instruction range guard per row); this text spends 9 per sample + 1.5 for the table lookup + ~9 per row.
 
 The row, for one lane = one (frame, channel) chain (reference: decode_one_slice_per_channel, src/lib.rs:291-330):
   bswap the slice words; scalefactor -> its row of the LDS PAIR table [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
