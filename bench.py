@@ -277,12 +277,14 @@ def main():
     if not args.no_decode:
         dplan = batch.DecodePlan.from_clips(clips)
         back = torch.empty_like(pcm)
-        for _ in range(8):  # untimed warm-up: after the host-side pause above the clocks need ~5 launches (8 ms) to settle
+        # untimed warm-up: after the host-side pause above the clocks keep rising for ~30 launches (40 ms) of this 1.5-ms
+        # kernel (kernel_ms_runs showed the 10 launches behind an 8-launch warm-up still falling by 5 %)
+        for _ in range(24):
             dplan.run(out, back, stream)
         # the timed launches are enqueued back to back like the encode steps (a host sync after every launch lets the
         # clocks sag between them: +5 % on this 1.6-ms kernel), one HIP event pair per launch
         d_events = []
-        for _ in range(max(10, args.steps)):
+        for _ in range(max(20, args.steps)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             dplan.run(out, back, stream)
@@ -358,10 +360,10 @@ def main():
             batch.EncodePlan(mclips).run(mpcm, menc, stream)
             mplan = batch.DecodePlan.from_clips(mclips)
             mback = torch.empty_like(mpcm)
-            for _ in range(8):
+            for _ in range(24):
                 mplan.run(menc, mback, stream)
             m_events = []
-            for _ in range(max(10, args.steps)):
+            for _ in range(max(20, args.steps)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream); mplan.run(menc, mback, stream); e1.record(stream)
                 m_events.append((e0, e1))
