@@ -697,14 +697,14 @@ struct DecTables {
     bool whole_pieces[kMaxChannels + 1] = {false};
     // K2u (qoa_decode.hip): uniform full frames of 1 / 2 channels whose PCM sits at a multiple of 16 bytes, in whole
     // wavefronts of 64 / channels frames; what does not fill a wavefront stays in frames[]
-    DevBuf uframes[3];
-    unsigned n_uframes[3] = {0};
+    DevBuf uframes[kMaxChannels + 1]; // K2u tables: channel counts with decode_uniform_group() != 0 (1, 2, 4, 8)
+    unsigned n_uframes[kMaxChannels + 1] = {0};
     DevBuf chains;
     unsigned n_chains = 0;
     DevBuf mismatch;
 
     // host copies of what upload() sends: they are the sources of asynchronous copies and live until the next upload
-    std::vector<DecChain> per[kMaxChannels + 1], generic, uni[3];
+    std::vector<DecChain> per[kMaxChannels + 1], generic, uni[kMaxChannels + 1];
 
     // sync = false: the copies are only enqueued on `stream`; the caller must not call upload() again before they ran
     hipError_t upload(const std::vector<DecChain> &recs, hipStream_t stream, bool sync = true) {
@@ -721,7 +721,8 @@ struct DecTables {
                 generic.push_back(e);
             }
         }
-        for (int n = 1; n <= 2; n++) {
+        for (int n = 1; n <= kMaxChannels; n++) {
+            if (!decode_uniform_group(n)) continue;
             std::vector<DecChain> rest;
             for (const DecChain &d : per[n]) {
                 const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 16 == 0;
@@ -735,7 +736,7 @@ struct DecTables {
         const bool fresh = mismatch.p == nullptr;
         hipError_t e = mismatch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
         if (e == hipSuccess && (fresh || sync)) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
-        for (int n = 1; n <= 2 && e == hipSuccess; n++) {
+        for (int n = 1; n <= kMaxChannels && e == hipSuccess; n++) {
             n_uframes[n] = (unsigned)uni[n].size();
             if (uni[n].empty()) continue;
             e = uframes[n].reserve(uni[n].size() * sizeof(DecChain));
@@ -761,8 +762,8 @@ struct DecTables {
         return e;
     }
     bool empty() const {
-        if (n_chains || n_uframes[1] || n_uframes[2]) return false;
-        for (int n = 1; n <= kMaxChannels; n++) if (n_frames[n]) return false;
+        if (n_chains) return false;
+        for (int n = 1; n <= kMaxChannels; n++) if (n_frames[n] || n_uframes[n]) return false;
         return true;
     }
     hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream, bool reset_mismatches = true) {
@@ -770,7 +771,7 @@ struct DecTables {
             hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
             if (e0 != hipSuccess) return e0;
         }
-        for (int n = 1; n <= 2; n++) {
+        for (int n = 1; n <= kMaxChannels; n++) {
             if (!n_uframes[n]) continue;
             // K2u stores 16-byte pieces at frame offsets that are multiples of 16: with an odd base pointer (a caller's
             // sub-buffer) the same table goes through the general kernel instead

@@ -436,8 +436,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 //    instead of recomputing it every row; a row it cannot prove exact executes nothing and reports flag = 1, the caller
 //    then checks exactly and either re-enters or takes the 32-bit step (rolled loop, cold).
 // LDS: 8.3 KB ring + 2.3 KB stage per wave (stereo), 16.6 + 2.6 KB (mono), + 4.8 KB of tables per block
-// -> 4-wave blocks, 12 (stereo) / 8 (mono) waves per CU.  (K2uCfg is written for 1, 2, 4 and 8 channels; rows are generated
-// for 1 and 2 only -- the general kernel already reaches 0.52-0.54 of peak at 4..8 channels, whose pieces are whole lines.)
+// -> 4-wave blocks, 12 (stereo) / 8 (mono) waves per CU.  K2uCfg and the generated rows cover 1, 2, 4 and 8 channels (the
+// divisors of a wavefront's 64 lanes; at 4 and 8 channels a round is a single staging unit and a single phase of 640 bytes):
+// 8 channels 1.69 -> 1.42 ms, 4 channels 0.91 -> 0.76-0.81 ms on 512 clips x 128 frames against the general kernel.
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
 struct K2uCfg {
@@ -589,7 +590,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 unit_top(std::integral_constant<int, row / HR>{}, row == 0 && round == 0,
                          row / HR == UNITS - 1 && round + 1 == kRounds);
             {
-                static_assert(NCH > 2 || RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : QOA_DEC_ASM_RING_2), "generated image offsets");
+                static_assert(RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 4 ? QOA_DEC_ASM_RING_4
+                                                                                                      : QOA_DEC_ASM_RING_8),
+                              "generated image offsets");
                 const uint2 raw = unit_raw[row % HR];
                 unsigned force = 0, flag = 0;
                 bool need_slow = false;
@@ -604,6 +607,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                        [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [lo16] "s"(-32768), [hi16] "v"(32767),        \
                        [force] "s"(force)                                                                              \
                      : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS);
+                    QOA_DEC_ROW_CASE(8, 0) QOA_DEC_ROW_CASE(8, 1)
+                    QOA_DEC_ROW_CASE(4, 0) QOA_DEC_ROW_CASE(4, 1) QOA_DEC_ROW_CASE(4, 2) QOA_DEC_ROW_CASE(4, 3)
                     QOA_DEC_ROW_CASE(2, 0) QOA_DEC_ROW_CASE(2, 1) QOA_DEC_ROW_CASE(2, 2) QOA_DEC_ROW_CASE(2, 3)
                     QOA_DEC_ROW_CASE(2, 4) QOA_DEC_ROW_CASE(2, 5) QOA_DEC_ROW_CASE(2, 6) QOA_DEC_ROW_CASE(2, 7)
                     QOA_DEC_ROW_CASE(1, 0) QOA_DEC_ROW_CASE(1, 1) QOA_DEC_ROW_CASE(1, 2) QOA_DEC_ROW_CASE(1, 3)
@@ -715,6 +720,8 @@ hipError_t launch_decode_uniform(int nch, const uint8_t *in, int16_t *out, const
     if (n_frames == 0) return hipSuccess;
     if (nch == 1) return launch_decode_uniform_n<1>(in, out, frames, n_frames, mismatches, stream);
     if (nch == 2) return launch_decode_uniform_n<2>(in, out, frames, n_frames, mismatches, stream);
+    if (nch == 4) return launch_decode_uniform_n<4>(in, out, frames, n_frames, mismatches, stream);
+    if (nch == 8) return launch_decode_uniform_n<8>(in, out, frames, n_frames, mismatches, stream);
     return hipErrorInvalidValue;
 }
 

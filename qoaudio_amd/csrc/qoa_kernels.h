@@ -33,9 +33,10 @@ hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *d_in,
                                 const DecChain *d_frames, unsigned n_frames, unsigned *d_mismatches,
                                 uint8_t *d_scratch, hipStream_t stream);
 
-// K2u, the fast path for uniform frames (rows == 256, n_out == 5120) of 1 or 2 channels: n_frames must be a multiple of
-// 64 / nch (whole wavefronts), every frame's PCM address 16-byte aligned.  kDecodeUniformFrames(nch) = that multiple.
-constexpr unsigned decode_uniform_group(int nch) { return nch == 1 ? 64u : nch == 2 ? 32u : 0u; }
+// K2u, the fast path for uniform frames (rows == 256, n_out == 5120) of 1, 2, 4 or 8 channels: n_frames must be a multiple
+// of 64 / nch (whole wavefronts), every frame's PCM address 16-byte aligned.  decode_uniform_group(nch) = that multiple
+// (0: no K2u for this channel count).
+constexpr unsigned decode_uniform_group(int nch) { return nch == 1 || nch == 2 || nch == 4 || nch == 8 ? 64u / (unsigned)nch : 0u; }
 hipError_t launch_decode_uniform(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames, unsigned n_frames,
                                  unsigned *d_mismatches, hipStream_t stream);
 

@@ -822,9 +822,9 @@ def test_host_decode_pipeline_and_persistent_handle(gpu, oracle, pinned):
     assert np.array_equal(rb.numpy()[:parts[0].size], oracle.decode_all(host_enc[:rclips[1][1]].tobytes())[2])
 
 
-@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("channels", [1, 2, 4, 8])
 def test_k2u_hostile_full_frames(gpu, oracle, channels):
-    """K2u (the fast path for full 256-row frames of 1 / 2 channels) on streams no encoder writes: random LMS headers and
+    """K2u (the fast path for full 256-row frames of 1 / 2 / 4 / 8 channels) on streams no encoder writes: random LMS headers and
     random slices (weights race out of i16 and back), frames that start from extreme header weights and push them further
     with all-ones slices, quiet music in between -- enough full frames for several wavefronts of the fast path plus a rest
     that takes the general kernel.  Every stream must equal the oracle's decoder sample for sample: the generated row's

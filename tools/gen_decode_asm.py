@@ -181,7 +181,7 @@ def emit(name, lines):
 
 
 # (channels, rows per round, image ring bytes): must agree with K2uCfg in qoa_decode.hip (static_asserts there)
-GEOMETRY = {1: (16, 256), 2: (8, 256)}
+GEOMETRY = {1: (16, 256), 2: (8, 256), 4: (4, 640), 8: (2, 640)}
 
 
 def render():
@@ -189,7 +189,7 @@ def render():
            "// QOA_DEC_ROW_TEXT_<channels>_<row of the round>: one slice row of K2u (20 samples of every chain of the wave) on",
            "// i16-packed weights / history; scratch v64-v94.  See the generator for operands and wait-state rules.",
            f"#define QOA_DEC_ROW_CLOBBERS " + ", ".join(f'"v{r}"' for r in CLOBBERS),
-           "#define QOA_DEC_ASM_RING_1 %d" % GEOMETRY[1][1], "#define QOA_DEC_ASM_RING_2 %d" % GEOMETRY[2][1], ""]
+           ] + ["#define QOA_DEC_ASM_RING_%d %d" % (n, GEOMETRY[n][1]) for n in GEOMETRY] + [""]
     n_lines = 0
     for nch, (rows, ring_bytes) in GEOMETRY.items():
         for row in range(rows):
