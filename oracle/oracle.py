@@ -90,6 +90,9 @@ def lib():
                                       C.POINTER(C.c_uint32)]
         L.oq_decoder_current_frame_header.argtypes = [C.c_void_p, C.POINTER(FrameHeader)]
         L.oq_decoder_next.argtypes = [C.c_void_p, C.POINTER(Item)]
+        L.oq_decoder_lms.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Lms)]
+        L.oq_decode_slice.argtypes = [C.POINTER(Lms), C.c_uint64, C.c_void_p, C.c_size_t]
+        L.oq_decode_slice.restype = None
         L.oq_decoder_decode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_size_t, C.POINTER(C.c_size_t)]
         L.oq_decode_all.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
@@ -194,6 +197,26 @@ def slice_rank_terms(history, weights, pcm):
     return tuple(list(x) for x in arrs)
 
 
+def slice_candidates(history, weights, pcm):
+    """The slice word each of the 16 scalefactor candidates produces when run to the end (no tail shift)."""
+    entry = Lms((C.c_int32 * 4)(*history), (C.c_int32 * 4)(*weights))
+    a, p = _pcm(pcm)
+    words = (C.c_uint64 * 16)()
+    L = lib()
+    L.oq_slice_candidates.argtypes = [C.POINTER(Lms), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.oq_slice_candidates.restype = None
+    L.oq_slice_candidates(C.byref(entry), p, 0, a.size, 1, words)
+    return list(words)
+
+
+def decode_slice(history, weights, slice_u64):
+    """One channel's slice from an explicit state (src/lib.rs:300-318): (int16[20], (history, weights) after it)."""
+    st = Lms((C.c_int32 * 4)(*history), (C.c_int32 * 4)(*weights))
+    out = np.empty(20, dtype=np.int16)
+    lib().oq_decode_slice(C.byref(st), slice_u64, out.ctypes.data_as(C.c_void_p), 1)
+    return out, (list(st.history), list(st.weights))
+
+
 def decode_all(data):
     """decode_all(reader) -> (channels, sample_rate, int16 ndarray)  (src/lib.rs:713-747)."""
     buf = np.frombuffer(bytes(data), dtype=np.uint8)
@@ -233,6 +256,13 @@ class OracleDecoder:
         ch, sr, n = C.c_uint8(0), C.c_uint32(0), C.c_uint32(0)
         m = lib().oq_decoder_mode(self.h, C.byref(ch), C.byref(sr), C.byref(n))
         return ("Streaming",) if m == 1 else ("FixedSamples", ch.value, sr.value, n.value)
+
+    def lms(self, channel):
+        """The decoder's predictor state of one channel (src/lib.rs:63): (history, weights)."""
+        st = Lms()
+        if lib().oq_decoder_lms(self.h, channel, C.byref(st)):
+            raise IndexError(channel)
+        return list(st.history), list(st.weights)
 
     def current_frame_header(self):
         h = FrameHeader()

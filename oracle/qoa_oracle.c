@@ -234,6 +234,21 @@ void oq_slice_rank_terms(const oq_lms *entry, const int16_t *pcm, size_t start, 
     }
 }
 
+/* Instrumentation for the whole-fixture pins: the slice word every candidate produces when run to the end (sf in the top
+ * 4 bits after slice_len shifts, src/lib.rs:549, :584; NOT yet left-aligned for a short tail, :485-487). */
+void oq_slice_candidates(const oq_lms *entry, const int16_t *pcm, size_t start, size_t end, size_t stride,
+                         uint64_t words[16]) {
+    int32_t samples[OQ_SLICE_LEN];
+    int slice_len = 0;
+    for (size_t si = start; si < end && slice_len < OQ_SLICE_LEN; si += stride) samples[slice_len++] = pcm[si];
+    for (int sf = 0; sf < 16; sf++) {
+        oq_lms l = *entry;
+        uint64_t s = (uint64_t)sf;
+        for (int i = 0; i < slice_len; i++) (void)candidate_step(&l, samples[i], sf, &s);
+        words[sf] = s;
+    }
+}
+
 /* src/lib.rs:335-361 */
 int oq_encoder_init(oq_encoder *e, const oq_desc *d, int search) {
     if (d->channels == 0 || d->channels > OQ_MAX_CHANNELS) return OQ_ENC_INVALID_CHANNELS;
@@ -427,6 +442,26 @@ static int decode_frame_header_and_lms(oq_decoder *d, int first) {
     return 1;
 }
 
+/* One channel's slice: the body of the per-channel loop of src/lib.rs:300-318 (scalefactor from the top 4 bits, 20 x
+ * predict / dequantise / clamp / update; the state is copied out, stepped, and stored back as at :302 and :316).
+ * Exposed for the whole-fixture pins (tests/test_oracle_golden.py): out[i * stride] receives sample i. */
+void oq_decode_slice(oq_lms *state, uint64_t slice, int16_t *out, size_t stride) {
+    int sf = (int)((slice >> 60) & 0xf);
+    oq_lms lms = *state;
+    size_t idx = 0;
+    for (int i = 0; i < OQ_SLICE_LEN; i++) {
+        int32_t prediction = lms_predict(&lms);
+        int quantized = (int)((slice >> 57) & 0x7);
+        int32_t dequantized = DEQUANT_TAB[sf][quantized];
+        int16_t reconstructed = (int16_t)clampi(prediction + dequantized, -32768, 32767);
+        out[idx] = reconstructed;
+        idx += stride;
+        slice <<= 3;
+        lms_update(&lms, reconstructed, dequantized);
+    }
+    *state = lms;
+}
+
 /* src/lib.rs:291-330.  Returns 0 or -(OQ_DEC_IO_ERROR) */
 static int decode_one_slice_per_channel(oq_decoder *d) {
     size_t channels = d->cur_header.num_channels;
@@ -439,20 +474,7 @@ static int decode_one_slice_per_channel(oq_decoder *d) {
     for (size_t c = 0; c < channels; c++) {
         uint64_t slice;
         if (rd_u64(d, &slice)) return -OQ_DEC_IO_ERROR;
-        int sf = (int)((slice >> 60) & 0xf);
-        oq_lms lms = d->lms[c];
-        size_t idx = c;
-        for (int i = 0; i < OQ_SLICE_LEN; i++) {
-            int32_t prediction = lms_predict(&lms);
-            int quantized = (int)((slice >> 57) & 0x7);
-            int32_t dequantized = DEQUANT_TAB[sf][quantized];
-            int16_t reconstructed = (int16_t)clampi(prediction + dequantized, -32768, 32767);
-            d->pending[idx] = reconstructed;
-            idx += channels;
-            slice <<= 3;
-            lms_update(&lms, reconstructed, dequantized);
-        }
-        d->lms[c] = lms;
+        oq_decode_slice(&d->lms[c], slice, d->pending + c, channels);
     }
     uint16_t n = d->remaining; /* :320-328 */
     if (n < OQ_SLICE_LEN) {
@@ -519,6 +541,13 @@ int oq_decoder_mode(const oq_decoder *d, uint8_t *channels, uint32_t *rate, uint
 }
 
 void oq_decoder_current_frame_header(const oq_decoder *d, oq_frame_header *h) { *h = d->cur_header; }
+
+/* test accessor: the decoder's per-channel predictor state (the `lms` field, src/lib.rs:63; written at :271-281, :316) */
+int oq_decoder_lms(const oq_decoder *d, size_t channel, oq_lms *out) {
+    if (channel >= d->lms_len) return -1;
+    *out = d->lms[channel];
+    return 0;
+}
 
 /* src/lib.rs:668-692 (the tail recursion there is a loop here) */
 void oq_decoder_next(oq_decoder *d, oq_item *item) {

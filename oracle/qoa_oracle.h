@@ -97,6 +97,10 @@ uint64_t oq_encode_slice(const oq_lms *entry, const int16_t *pcm, size_t start, 
 void oq_slice_rank_terms(const oq_lms *entry, const int16_t *pcm, size_t start, size_t end, size_t stride,
                          uint64_t err_sq[16], uint64_t pen_sq[16], uint64_t first_err_sq[16], uint64_t first_pen_sq[16]);
 
+/* instrumentation: the slice word of each of the 16 candidates run to the end (before the tail's left shift) */
+void oq_slice_candidates(const oq_lms *entry, const int16_t *pcm, size_t start, size_t end, size_t stride,
+                         uint64_t words[16]);
+
 /* ---- decoder: src/lib.rs:59-68, 127-330, 627-693 ---- */
 
 /* FrameHeader, src/lib.rs:774-781 */
@@ -126,6 +130,10 @@ void oq_decoder_free(oq_decoder *d);
 int oq_decoder_mode(const oq_decoder *d, uint8_t *channels, uint32_t *rate, uint32_t *samples); /* :180-182 */
 void oq_decoder_current_frame_header(const oq_decoder *d, oq_frame_header *h); /* src/lib.rs:186-188 */
 void oq_decoder_next(oq_decoder *d, oq_item *item);                            /* src/lib.rs:668-692 */
+/* test accessors for the whole-fixture pins (oracle/README.md): the decoder's per-channel LMS state (src/lib.rs:63) and one
+ * channel's slice stepped from an explicit state (src/lib.rs:300-318); out[i * stride] = sample i. */
+int oq_decoder_lms(const oq_decoder *d, size_t channel, oq_lms *out);
+void oq_decode_slice(oq_lms *state, uint64_t slice, int16_t *out, size_t stride);
 /* decode_frame: appends bytes to the reader and drains the iterator.  src/lib.rs:641-651.
  * out may be NULL to query the count; returns 0 or OQ_DEC_* (samples decoded before an error are lost,
  * as in the reference, but *n_out still reports how many were produced). */

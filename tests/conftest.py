@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(1, os.path.join(ROOT, "tests"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 FIXTURE = os.path.join(GOLDEN, "julien_baker_sprained_ankle.qoa")
@@ -46,6 +48,13 @@ def fixture_pcm(oracle, fixture_bytes):
     ch, sr, pcm = oracle.decode_all(fixture_bytes)
     assert (ch, sr, pcm.size) == (2, 44100, 2394122 * 2)
     return pcm
+
+
+@pytest.fixture(scope="session")
+def fixture_walk(oracle, fixture_bytes):
+    """(slices, boundaries) of the fixture's own decode trajectory: tests/fixture_walk.py."""
+    import fixture_walk as W
+    return W.walk(oracle, fixture_bytes)
 
 
 @pytest.fixture(scope="session")

@@ -358,6 +358,41 @@ def test_kat2_slice_search_lane_by_lane(gpu, oracle):
         assert (win, dev_win, hex(sl[win])) == (5, 5, "0x56484f1ce06cd14a")
 
 
+def test_fixture_slices_teacher_forced_on_device(gpu, oracle, fixture_walk):
+    """Device mirror of tests/test_oracle_golden.py::test_fixture_slices_teacher_forced: slices of the reference-held
+    fixture, each from the entry state of the fixture's own decode trajectory, through the device functions of K1 in all
+    four forms of qoa_debug_encode_slice.  All 1,055 slices where the fixture's older, penalty-free encoder and the crate's
+    rule differ (the only reference-adjacent penalty-decided cases that exist) plus every 97th slice and the 2-sample
+    tail.  Per slice: all 16 total ranks equal the oracle's, the device's winner is the oracle's, and the device's
+    candidate for the FIXTURE's scalefactor is the fixture's slice word bit for bit."""
+    import fixture_walk as W
+    slices, _ = fixture_walk
+    others = []
+    for i, s in enumerate(slices):
+        word, sf, _st, _ = oracle.encode_slice(s["entry"][0], s["entry"][1], s["pcm"], oracle.EXHAUSTIVE)
+        if (word << ((20 - s["n"]) * 3)) & (2 ** 64 - 1) != s["word"]:
+            others.append(i)
+    assert len(others) == 1055
+    other_set = set(others)
+    picks = sorted(set(others) | set(range(0, len(slices), 97)) | {len(slices) - 1, len(slices) - 2})
+    declined = 0
+    for i in picks:
+        s = slices[i]
+        state = list(s["entry"][0]) + list(s["entry"][1])
+        word, sf, (eh, ew), totals = oracle.encode_slice(s["entry"][0], s["entry"][1], s["pcm"], oracle.REF_STYLE)
+        sf_fix = s["word"] >> 60
+        assert (sf != sf_fix) == (i in other_set)
+        for generic in (0, 1, 2, 3):
+            tot, aerr0, sl, es, dev_win = _gpu_slice(state, s["pcm"], generic)
+            assert tot == totals, (i, generic)
+            assert dev_win == sf, (i, generic)
+            assert sl[sf_fix] == s["word"], (i, generic)
+            assert list(es[sf]) == eh + ew
+            declined += generic == 3 and _gpu_slice.declined
+    # the packed form must carry practically all of it (real music): a silent fall-back would halve K1's speed
+    assert declined < len(picks) // 20
+
+
 def test_candidate_ranks_match_oracle_on_hard_slices(gpu, oracle):
     """err^2 reaches 2^32 and the 64-bit rank sums carry on full-scale input; weights/history at extremes."""
     r = np.random.default_rng(5)

@@ -83,6 +83,58 @@ def test_kat1_prefix_penalty_coverage(oracle, fixture_pcm):
     assert (slices, pen_winner, pen_any, decided, tied) == (132920, 866, 1022, 0, 0)
 
 
+# ---- whole-fixture pins: every frame boundary and every slice of the reference-held file (oracle/README.md) ----
+
+def _i16(v):
+    return ((v + 32768) & 0xffff) - 32768
+
+
+def test_fixture_frame_headers_chain(fixture_walk):
+    """Decoder pin, independent of any encoder rule.  The fixture's encoder wrote its carried LMS state into every frame
+    header (history and weights as 16-bit images, src/lib.rs:455-466); a decoder that follows src/lib.rs:271-281 and
+    :300-318 must arrive at exactly that state at the end of the frame before: history exactly, weights modulo 2^16.  468
+    frames x 2 channels give 467 x 2 boundaries; all of them hold, so predict / dequantise / clamp / update are pinned over
+    the whole file, not only over KAT-1's 259-frame prefix."""
+    _slices, boundaries = fixture_walk
+    assert len(boundaries) == 934
+    ok = sum(1 for _k, _c, end, hdr in boundaries if end[0] == hdr[0] and [_i16(w) for w in end[1]] == hdr[1])
+    assert ok == 934
+
+
+@pytest.mark.parametrize("search", [0, 1], ids=["ref_style", "exhaustive"])
+def test_fixture_slices_teacher_forced(oracle, fixture_walk, search):
+    """Encoder pin over all 239,414 slices.  Each slice is encoded from the state the FIXTURE's trajectory enters it with
+    (so one differing winner cannot hide what follows, as it does behind KAT-1's first divergence) over the samples the
+    fixture decodes to.  238,359 slices come out byte-identical.  In every one of the other 1,055 the fixture's scalefactor
+    is the argmin of (sum err^2, first err^2, sf) -- the search of src/lib.rs:516-593 WITHOUT the weights-penalty term
+    (:814-817), which the older encoder that wrote the file did not have -- and the fixture's slice word is, bit for bit,
+    what this restatement's candidate for that scalefactor produces.  So the quantise / dequantise / update chain and the
+    err^2 ranking are pinned by reference-held bytes on every slice of the file; the penalty term alone rests on the
+    agreement of independent restatements (oracle/README.md)."""
+    slices, _ = fixture_walk
+    assert len(slices) == 239414
+    equal, others = 0, []
+    for i, s in enumerate(slices):
+        word, _sf, _st, _ = oracle.encode_slice(s["entry"][0], s["entry"][1], s["pcm"], search)
+        word = (word << ((20 - s["n"]) * 3)) & (2 ** 64 - 1)  # src/lib.rs:485-487
+        if word == s["word"]:
+            equal += 1
+        else:
+            others.append(i)
+    assert (equal, len(others)) == (238359, 1055)
+    beyond_kat1 = sum(1 for s in slices if 8 + s["frame"] * 4136 + 40 + 8 * (s["row"] * 2 + s["ch"]) >= KAT1_PREFIX)
+    assert beyond_kat1 == 239414 - 132920
+    import fixture_walk as W
+    for i in others:
+        s = slices[i]
+        sf_fix = s["word"] >> 60
+        assert W.penalty_free_argmin(oracle, s["entry"], s["pcm"]) == sf_fix
+        cand = oracle.slice_candidates(s["entry"][0], s["entry"][1], s["pcm"])[sf_fix]
+        assert (cand << ((20 - s["n"]) * 3)) & (2 ** 64 - 1) == s["word"]
+        e, p, _fe, _fp = oracle.slice_rank_terms(s["entry"][0], s["entry"][1], s["pcm"])
+        assert p[sf_fix] > 0  # the fixture's choice carries a penalty: that is why the crate's rule leaves it
+
+
 def test_kat2_slice_search(oracle):
     s, sf, (hist, weights), totals = oracle.encode_slice(
         [-2655, -1631, -965, -806], [-5363, 11763, -15085, 16783],
