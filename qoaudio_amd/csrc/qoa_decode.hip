@@ -5,7 +5,10 @@
 
 #include "qoa_device.h"
 #include "qoa_kernels.h"
-#include "qoa_decode_asm.inc"
+#ifndef QOA_DEC_ASM_INC
+#define QOA_DEC_ASM_INC "qoa_decode_asm.inc"
+#endif
+#include QOA_DEC_ASM_INC
 
 #ifndef QOA_DEC_DEPTH
 #define QOA_DEC_DEPTH 2
@@ -444,7 +447,11 @@ template <int NCH>
 struct K2uCfg {
     static constexpr int FPW = 64 / NCH;                 // frames (groups) per wave
     static constexpr int RR = 16 / NCH;                  // rows per round: 128 B of slices, 640 B (5 lines) of PCM per frame
+#ifdef QOA_K2U_HR2
+    static constexpr int HR = NCH == 2 ? QOA_K2U_HR2 : NCH == 1 ? 4 : RR;
+#else
     static constexpr int HR = NCH == 1 ? 4 : NCH == 2 ? 4 : RR;         // rows per staging unit
+#endif
     static constexpr int PR = NCH == 1 ? 4 : NCH == 2 ? 2 : (RR < 4 ? RR : 4); // rows per phase (flush granularity)
     static constexpr int PB = PR * 40 * NCH;             // PCM bytes per frame per phase
     static constexpr int ring() { // whole lines, >= one phase + the largest carried partial line
@@ -453,12 +460,40 @@ struct K2uCfg {
         return (PB + carry + 127) / 128 * 128;
     }
     static constexpr int RING = ring();
-    static constexpr int GSP = RING + 4;                 // odd dword stride: conflict-free 2-byte scatter across groups
+    static constexpr bool QUAD = NCH == 1 ? QOA_DEC_ROW_QUAD_1 : NCH == 2 ? QOA_DEC_ROW_QUAD_2 : NCH == 4 ? QOA_DEC_ROW_QUAD_4
+                                                                                                 : QOA_DEC_ROW_QUAD_8;
+    // Ring stride per frame.  Mono: an odd number of dwords -- 32 frames of a half-wave scatter into 32 different banks.
+    // Otherwise RING + 16: the flush reads whole 16-byte pieces with ONE ds_read_b128 each (4 x ds_read_b32 before), and the
+    // 2-byte scatter of a half-wave (at most 16 frames, stride 17 or 41 sixteen-byte units) meets at most 2 frames per bank,
+    // which a ds_write hides behind its own data transfer (MI355X_MICROARCH.md, LDS: "2-way on ds_write_b32 costs nothing").
+#ifdef QOA_K2U_GSP_PAD
+    static constexpr int GSP = RING + QOA_K2U_GSP_PAD;
+#else
+    static constexpr int GSP = RING + (NCH == 1 ? 4 : 16);
+#endif
+    // staging units in flight: the slices of unit n + NSLOT are requested at the top of unit n (each slot is one unit's
+    // lane-linear LDS-DMA image)
+#ifdef QOA_K2U_NSLOT
+    static constexpr int NSLOT = QOA_K2U_NSLOT;
+#else
+    static constexpr int NSLOT = 1;
+#endif
+    // waves per block: the quad form's 16 KB table wants to be shared by as many waves as the CU holds (multiples of 4 only:
+    // other counts load the four SIMDs unevenly -- profiles/r02_k2lab_log.md, run 20)
+    static constexpr int WPB = !QUAD ? 4 : NCH == 8 ? 16 : NCH == 4 ? 8 : 12;
+    // vector-memory operations younger than unit n's loads at the top of unit n (steady state): the loads of the NSLOT - 1
+    // units requested since, and the stores of the NSLOT units since
+    static constexpr int behind(int u) {
+        int n = (NSLOT - 1) * NLD;
+        constexpr int units = RR / HR;
+        for (int k = 1; k <= NSLOT; k++) n += unit_stores(((u - k) % units + units) % units);
+        return n;
+    }
     static constexpr int NLS = FPW / 8;                  // store instructions per line (8 lanes = one 128-byte line of one frame)
     static constexpr int CB = HR * 8 * NCH;              // slice bytes per frame per staging unit (64 or 128)
     static constexpr int LPC = CB / 16;                  // lanes per frame chunk
     static constexpr int NLD = FPW * CB / 1024;          // load instructions per staging unit
-    static constexpr int SSP = CB + 8;                   // stage stride per frame
+    static constexpr int SSP = CB;                       // stage stride per frame: lane-linear, as the LDS-DMA writes it
     static constexpr int lines_done(int rows) { return (rows * 40 * NCH) / 128; } // lines complete after `rows` rows of the round
     // store instructions issued during staging unit u (rows [u*HR, (u+1)*HR) of the round)
     static constexpr int unit_stores(int u) {
@@ -467,34 +502,50 @@ struct K2uCfg {
             if ((row + 1) % PR == 0) n += (lines_done(row + 1) - lines_done(row + 1 - PR)) * NLS;
         return n;
     }
-    static_assert(RR % HR == 0 && HR % PR == 0 && NLD >= 1 && CB % 16 == 0, "K2u geometry");
+    static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (FPW * CB) % 1024 == 0,
+                  "K2u geometry");
 };
 
+#ifndef QOA_K2U_LOAD_POLICY
+#define QOA_K2U_LOAD_POLICY ""
+#endif
+#ifndef QOA_K2U_WPB_OVERRIDE
+#define QOA_K2U_WPB_OVERRIDE 0
+#endif
 template <int NCH, int WPB>
 __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
                                                                      const DecChain *__restrict__ frames, unsigned n_frames,
                                                                      unsigned *__restrict__ mismatches) {
     typedef K2uCfg<NCH> C;
     constexpr int FPW = C::FPW, RR = C::RR, HR = C::HR, PR = C::PR, RING = C::RING, GSP = C::GSP, NLS = C::NLS, NLD = C::NLD,
-                  SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR;
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + 12];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][FPW * SSP];
+                  SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = FPW * SSP;
+    constexpr bool QUAD = C::QUAD;
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + (NCH == 1 ? 12 : 16)];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][NSLOT * SLOT];
     __shared__ uint2 s_mags[16];
-    // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
-    __shared__ __attribute__((aligned(256))) unsigned s_deq2[16][64];
+    // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16, or in the
+    // quad form {deq(a) >> 4 (16 bits, zero-extended), deq(a), deq(b) >> 4, deq(b)} (gen_decode_asm.py)
+    __shared__ __attribute__((aligned(256))) unsigned s_deq2[16][QUAD ? 256 : 64];
     __shared__ int s_grow[16]; // 20 * ceil(mag3(sf) / 16): the most one row can move a weight
     for (unsigned t = threadIdx.x; t < 1024; t += blockDim.x) {
         const unsigned sf = t >> 6, a = (t >> 3) & 7u, b = t & 7u;
         const int da = (a & 1u) ? -c_mags[sf][a >> 1] : c_mags[sf][a >> 1]; // QOA_DEQUANT_TAB, src/lib.rs:847-864
         const int db = (b & 1u) ? -c_mags[sf][b >> 1] : c_mags[sf][b >> 1];
-        s_deq2[sf][t & 63u] = ((unsigned)da & 0xffffu) | ((unsigned)db << 16);
+        if constexpr (QUAD) {
+            unsigned *e = &s_deq2[sf][(t & 63u) * 4];
+            e[0] = (unsigned)(da >> 4) & 0xffffu; e[1] = (unsigned)da; // the weight step of src/lib.rs:822 beside the value
+            e[2] = (unsigned)(db >> 4) & 0xffffu; e[3] = (unsigned)db;
+        } else {
+            s_deq2[sf][t & 63u] = ((unsigned)da & 0xffffu) | ((unsigned)db << 16);
+        }
     }
     if (threadIdx.x < 16) s_grow[threadIdx.x] = 20 * ((c_mags[threadIdx.x][3] + 15) >> 4);
     init_mag_table(s_mags); // (ends with the block barrier)
 
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned g = lane / NCH, c = lane % NCH;
-    const unsigned frame0 = (blockIdx.x * (unsigned)WPB + wave) * FPW; // the launcher guarantees frame0 + FPW <= n_frames
+    const unsigned frame0 = (blockIdx.x * (unsigned)WPB + wave) * FPW;
+    if (frame0 + FPW > n_frames) return; // a wave of the last block beyond the table (behind the only barrier)
     const DecChain fr = frames[frame0 + g];
     const uint8_t *f = in + fr.frame_off;
     Lms l;
@@ -535,27 +586,23 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         }
     }
     const unsigned oct_img = (lane / 8u) * GSP + (lane % 8u) * 16u;                       // + o*8*GSP + ring offset of the line
-    const unsigned ld_stage = (lane / (unsigned)LPC) * SSP + (lane % (unsigned)LPC) * 16u; // + q*(64/LPC)*SSP
+    typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
 
-    // asynchronous slice loads into AccVGPRs a[4q : 4q+3] (registers hipcc never allocates here: a load in flight
-    // cannot be broken by a compiler-made copy; tests/test_k2_disasm.py checks that nothing else touches them)
-    auto issue_loads = [&]() {
+    // Asynchronous slice loads: LDS-DMA (global_load_lds_dwordx4) straight into the wave's stage -- lane L of instruction q
+    // lands at stage + q * 1024 + L * 16, which with the load roles above IS the frame-major stage [frame][CB bytes].  No
+    // register holds a load in flight, so nothing the compiler does between issue and wait can break it, and the kernel
+    // uses no AccVGPRs (with them hipcc gives a 768-thread block only half of its 168 registers as VGPRs).  M0 = destination
+    // base; it is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md, inline-asm notes).
+    const unsigned stage_m0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)stage);
+    auto issue_loads = [&](unsigned slot_off) { // slot_off: wave-uniform byte offset of the destination slot
         static_for<0, NLD>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            if constexpr (NLD > 4)
-                asm volatile("global_load_dwordx4 a[%1:%2], %0, off" : : "v"(in_ptr[q]), "n"(4 * q), "n"(4 * q + 3) : "memory",
-                             "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15",
-                             "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-            else if constexpr (NLD > 2)
-                asm volatile("global_load_dwordx4 a[%1:%2], %0, off" : : "v"(in_ptr[q]), "n"(4 * q), "n"(4 * q + 3) : "memory",
-                             "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-            else
-                asm volatile("global_load_dwordx4 a[%1:%2], %0, off" : : "v"(in_ptr[q]), "n"(4 * q), "n"(4 * q + 3) : "memory",
-                             "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" QOA_K2U_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(in_ptr[q]), "s"(stage_m0 + slot_off + (unsigned)(q * 1024)) : "memory");
             in_ptr[q] += CB;
         });
     };
-    typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
     uint2 unit_raw[HR]; // the unit's slices of this chain, read back from the stage at the unit top
     (void)unit_raw;
     const unsigned tab_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_deq2[0][0];
@@ -563,32 +610,46 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     const unsigned img_lds = (unsigned)(size_t)(lds_ptr)img + my_img;
     int slack = dec_slack(pk);
     (void)tab_lds; (void)grow_lds; (void)img_lds; (void)slack;
-    const unsigned stage_lds = (unsigned)(size_t)(lds_ptr)stage + ld_stage;
-    // unit top: the unit's slices have arrived (behind them: only the stores of the previous unit); park them in the
-    // LDS stage and request the next unit's
-    auto unit_top = [&](auto uc, bool first, bool last) {
+#ifdef QOA_K2U_LAB_PREFETCH
+    const unsigned long long pf_base = (unsigned long long)(in + frames[frame0].frame_off + 8 + 16 * NCH); // frames assumed consecutive
+    for (unsigned j = 0; j < (unsigned)FPW; j++) {
+        const unsigned long long a = pf_base + j * (8 + 16 * NCH + 2048 * NCH) + lane * 16;
+        asm volatile("global_load_dwordx4 a[0:3], %0, off" : : "v"(a) : "memory", "a0", "a1", "a2", "a3");
+    }
+#endif
+    constexpr unsigned kRounds = 256 / RR, kUnits = kRounds * UNITS;
+    static_assert(kUnits > 2 * NSLOT, "staging depth");
+    // unit top (n = the unit's number in the frame): its slices have landed in slot n % NSLOT -- behind them in the vmcnt
+    // order are only the C::behind(u) younger operations of the steady state; the first and last NSLOT units, where fewer
+    // are in flight, simply drain -- every lane takes its own rows out, and once those reads are back the DMA of unit
+    // n + NSLOT may overwrite the slot
+    auto unit_top = [&](auto uc, unsigned n) {
         constexpr int u = decltype(uc)::value;
-        constexpr int behind = C::unit_stores((u + UNITS - 1) % UNITS);
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(behind) : "memory");
-        static_for<0, NLD>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            unsigned sa_q = stage_lds + (unsigned)(q * (64 / LPC) * SSP);
-            asm volatile("ds_write2_b64 %0, a[%1:%2], a[%3:%4] offset1:1" : : "v"(sa_q), "n"(4 * q), "n"(4 * q + 1),
-                         "n"(4 * q + 2), "n"(4 * q + 3) : "memory");
-        });
-        if (!last) issue_loads();
+        if (n < (unsigned)NSLOT || n + NSLOT > kUnits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(C::behind(u)) : "memory");
+        const unsigned slot_off = NSLOT == 1 ? 0u : (n % NSLOT) * SLOT;
+#ifdef QOA_K2U_LAB_PREFETCH // lab: every 1 KB of a frame's slices is pulled towards L2/MALL in ONE contiguous read, a quarter frame ahead
+        if ((n * CB) % 1024 == 0 && (n * CB) / 1024 + 1 < 2 * NCH) {
+            const unsigned long long q0 = pf_base + ((n * CB) / 1024 + 1) * 1024 + lane * 16;
+            for (unsigned j = 0; j < (unsigned)FPW; j++) {
+                const unsigned long long a = q0 + j * (8 + 16 * NCH + 2048 * NCH);
+                asm volatile("global_load_dwordx4 a[0:3], %0, off" : : "v"(a) : "memory", "a0", "a1", "a2", "a3");
+            }
+        }
+#endif
 #pragma unroll
-        for (int r = 0; r < HR; r++) unit_raw[r] = *(const uint2 *)(stage + my_stage + r * NCH * 8);
+        for (int r = 0; r < HR; r++) unit_raw[r] = *(const uint2 *)(stage + slot_off + my_stage + r * NCH * 8);
+        if (n + NSLOT < kUnits) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // WAR: the reads above before the DMA below
+            issue_loads(slot_off);
+        }
     };
-    issue_loads();
-    constexpr unsigned kRounds = 256 / RR;
+    for (unsigned n = 0; n < (unsigned)NSLOT; n++) issue_loads(n * SLOT);
     for (unsigned round = 0; round < kRounds; round++) {
         static_for<0, RR>([&](auto rc) {
             constexpr int row = decltype(rc)::value; // row within the round
             if constexpr (row % HR == 0)
-                unit_top(std::integral_constant<int, row / HR>{}, row == 0 && round == 0,
-                         row / HR == UNITS - 1 && round + 1 == kRounds);
+                unit_top(std::integral_constant<int, row / HR>{}, round * UNITS + row / HR);
             {
                 static_assert(RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 4 ? QOA_DEC_ASM_RING_4
                                                                                                       : QOA_DEC_ASM_RING_8),
@@ -596,6 +657,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 const uint2 raw = unit_raw[row % HR];
                 unsigned force = 0, flag = 0;
                 bool need_slow = false;
+#ifdef QOA_K2U_LAB_NOCOMPUTE // lab: the memory skeleton alone (the slices are consumed by one LDS write so that they are not dead)
+                *(volatile unsigned *)(img + my_img) = raw.x ^ raw.y;
+                if (false)
+#endif
 #pragma unroll 1
                 for (;;) {
 #define QOA_DEC_ROW_CASE(N, R)                                                                                         \
@@ -604,9 +669,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                      : [w01] "+v"(pk.w01), [w23] "+v"(pk.w23), [pa] "+v"(pk.pa), [pm] "+v"(pk.pm), [pb] "+v"(pk.pb),   \
                        [sa] "+v"(pk.sa), [sm] "+v"(pk.sm), [sb] "+v"(pk.sb), [slack] "+v"(slack), [flag] "=s"(flag)    \
                      : [rx] "v"(raw.x), [ry] "v"(raw.y), [tab] "s"(tab_lds), [grow] "s"(grow_lds), [img] "v"(img_lds),  \
-                       [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [lo16] "s"(-32768), [hi16] "v"(32767),        \
-                       [force] "s"(force)                                                                              \
-                     : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS);
+                       [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [k19] "s"(0x80000), [force] "s"(force)       \
+                     : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS_##N);
                     QOA_DEC_ROW_CASE(8, 0) QOA_DEC_ROW_CASE(8, 1)
                     QOA_DEC_ROW_CASE(4, 0) QOA_DEC_ROW_CASE(4, 1) QOA_DEC_ROW_CASE(4, 2) QOA_DEC_ROW_CASE(4, 3)
                     QOA_DEC_ROW_CASE(2, 0) QOA_DEC_ROW_CASE(2, 1) QOA_DEC_ROW_CASE(2, 2) QOA_DEC_ROW_CASE(2, 3)
@@ -643,6 +707,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 // flush the lines this phase completed
                 constexpr int l0 = C::lines_done(row + 1 - PR), l1 = C::lines_done(row + 1);
                 typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+                typedef unsigned u4_piece __attribute__((ext_vector_type(4), aligned(16), may_alias));
                 typedef unsigned u32_alias __attribute__((may_alias));
                 asm volatile("" ::: "memory"); // the image was written as int16: keep the dword reads below behind those stores
                 static_for<0, NLS>([&](auto oc) {
@@ -650,8 +715,13 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     u4_unaligned v[l1 - l0 > 0 ? l1 - l0 : 1];
 #pragma unroll
                     for (int ln = l0; ln < l1; ln++) {
-                        const u32_alias *src = (const u32_alias *)(img + oct_img + o * 8 * GSP + (ln * 128) % RING);
-                        v[ln - l0] = u4_unaligned{src[0], src[1], src[2], src[3]};
+                        if constexpr (GSP % 16 == 0) { // 16-byte aligned pieces: one ds_read_b128
+                            const u4_piece x = *(const u4_piece *)(img + oct_img + o * 8 * GSP + (ln * 128) % RING);
+                            v[ln - l0] = u4_unaligned{x[0], x[1], x[2], x[3]};
+                        } else {
+                            const u32_alias *src = (const u32_alias *)(img + oct_img + o * 8 * GSP + (ln * 128) % RING);
+                            v[ln - l0] = u4_unaligned{src[0], src[1], src[2], src[3]};
+                        }
                     }
 #pragma unroll
                     for (int ln = l0; ln < l1; ln++) {
@@ -703,15 +773,20 @@ template <int NCH>
 static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
                                           unsigned *mismatches, hipStream_t stream) {
     constexpr unsigned FPW = 64 / NCH;
+    constexpr unsigned W = QOA_K2U_WPB_OVERRIDE ? QOA_K2U_WPB_OVERRIDE : K2uCfg<NCH>::WPB;
     const unsigned waves = n_frames / FPW; // the plan only puts whole wavefronts of frames into this table
     if (waves * FPW != n_frames) return hipErrorInvalidValue;
-    const unsigned blocks4 = waves / 4, rest = waves % 4;
-    if (blocks4)
-        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, 4>), dim3(blocks4), dim3(256), 0, stream, in, out, frames,
-                           blocks4 * 4 * FPW, mismatches);
-    if (rest)
-        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, 1>), dim3(rest), dim3(64), 0, stream, in, out,
-                           frames + (size_t)blocks4 * 4 * FPW, rest * FPW, mismatches);
+    // ONE launch: the last block may be short of waves (they leave behind the table barrier).  A second, small launch for the
+    // remainder would run after the first on the stream, alone on the chip, for as long as a full wave takes: +0.25 ms.
+    // Block size by how far the work fills the chip: big blocks (one table for W waves) only when every CU gets one.
+    auto go = [&](auto wc) {
+        constexpr unsigned w = decltype(wc)::value;
+        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, w>), dim3((waves + w - 1) / w), dim3(64 * w), 0, stream, in, out,
+                           frames, n_frames, mismatches);
+    };
+    if (waves >= 256u * W) go(std::integral_constant<unsigned, W>{});
+    else if (waves >= 256u * 4u) go(std::integral_constant<unsigned, 4>{});
+    else go(std::integral_constant<unsigned, 1>{});
     return hipGetLastError();
 }
 

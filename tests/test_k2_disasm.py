@@ -57,7 +57,9 @@ def _decode_kernels(tmp_path):
         for line in text.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
             if m:
-                name = m.group(1)
+                # the asm statements' local labels (Lqoa_*) are ELF symbols too: they do not end the kernel they sit in
+                if not m.group(1).startswith("Lqoa_"):
+                    name = m.group(1)
                 continue
             if name and "qoa_decode" in name and line.strip():
                 ins = line.split("//")[0].strip()

@@ -60,8 +60,18 @@ int main(int argc, char **argv) {
     size_t n_clips = argc > 2 ? atol(argv[2]) : 1024;
     size_t frames = argc > 3 ? atol(argv[3]) : 256;
     int runs = argc > 4 ? atoi(argv[4]) : 5;
+    // experiment knob: every clip's frames are read from the encoded bytes of clip (c % in_wrap) -- in_wrap = 2 keeps the whole
+    // input resident in each XCD's L2 (the PCM then differs from the product's decode: timing only)
+    size_t in_wrap = argc > 5 ? atol(argv[5]) : 0;
+    // experiment knob: frames re-laid out at a stride of `pad_stride` bytes (multiple of 128) so that every frame's slice
+    // area (frame + 8 + 16 * nch) starts on a 128-byte line: what would whole-line slice loads buy?
+    size_t pad_stride = argc > 6 ? atol(argv[6]) : 0;
+    // experiment knob: output frames `out_pad` bytes apart instead of contiguous (5120 * nch * 2): is the power-of-two-ish
+    // frame stride of the PCM (20480 B for stereo) a channel/bank camping problem?  (timing only)
+    size_t out_pad = argc > 7 ? atol(argv[7]) : 0;
     const size_t fsize = 8 + 16 * nch + 8 * 256 * nch;
-    const size_t per_enc = 8 + frames * fsize, per_pcm = frames * 5120 * nch;
+    const size_t out_pad_early = argc > 7 ? atol(argv[7]) : 0;
+    const size_t per_enc = 8 + frames * fsize, per_pcm = frames * (5120 * nch + out_pad_early / 2);
     unsigned char *enc; int16_t *pcm; unsigned *mm; unsigned char *scratch; unsigned long long *cs;
     size_t enc_bytes = (n_clips * per_enc + 15) / 16 * 16;
     CK(hipMalloc(&enc, enc_bytes)); CK(hipMalloc(&pcm, n_clips * per_pcm * 2)); CK(hipMalloc(&mm, 4));
@@ -78,11 +88,21 @@ int main(int argc, char **argv) {
         qoa_encode_plan_free(ep);
         CK(hipMemset(pcm, 0, n_clips * per_pcm * 2));
     }
+    unsigned char *enc_pad = nullptr;
+    const size_t lead = 128 - (8 + 16 * nch) % 128; // frame starts `lead` bytes into a line
+    if (pad_stride) {
+        CK(hipMalloc(&enc_pad, n_clips * frames * pad_stride + 256));
+        for (size_t c = 0; c < n_clips; c++)
+            CK(hipMemcpy2DAsync(enc_pad + lead + c * frames * pad_stride, pad_stride, enc + c * per_enc + 8, fsize, fsize, frames,
+                                hipMemcpyDeviceToDevice, 0));
+        CK(hipDeviceSynchronize());
+    }
     std::vector<qoa::DecChain> tab(n_clips * frames);
     for (size_t c = 0; c < n_clips; c++)
         for (size_t f = 0; f < frames; f++) {
             qoa::DecChain &d = tab[c * frames + f];
-            d.frame_off = c * per_enc + 8 + f * fsize; d.out_off = c * per_pcm + f * 5120 * nch; d.n_out = 5120; d.rows = 256;
+            d.frame_off = (in_wrap ? c % in_wrap : c) * per_enc + 8 + f * fsize;
+            if (pad_stride) d.frame_off = lead + ((in_wrap ? c % in_wrap : c) * frames + f) * pad_stride; d.out_off = c * per_pcm + f * (5120 * nch + out_pad / 2); d.n_out = 5120; d.rows = 256;
             d.channels = (uint8_t)nch; d.channel = 0; d.expect_hi = d.expect_lo = 0;
         }
     qoa::DecChain *dtab; CK(hipMalloc(&dtab, tab.size() * sizeof(qoa::DecChain)));
@@ -93,7 +113,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < runs + 1; i++) {
         (void)hipEventRecord(e0, 0);
 #ifdef LAB_UNIFORM
-        CK(qoa::launch_decode_uniform(nch, enc, pcm, dtab, (unsigned)tab.size(), mm, 0));
+        CK(qoa::launch_decode_uniform(nch, pad_stride ? enc_pad : enc, pcm, dtab, (unsigned)tab.size(), mm, 0));
 #else
         CK(qoa::launch_decode_frames(nch, true, enc, pcm, dtab, (unsigned)tab.size(), mm, scratch, 0));
 #endif
