@@ -413,35 +413,38 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2u: the fast path for UNIFORM frames -- rows == 256 and n_out == 5120 (every frame of a clip but its last), 1 or 2
-// channels, 16-byte aligned PCM.  Everything else (short frames, 3..8 channels, odd alignments, hostile streams) stays
-// on qoa_decode_frames_kernel above; the plan splits its frame table accordingly (qoa_capi.cpp, DecTables).
+// K2u: the fast path for UNIFORM frames -- rows == 256 and n_out == 5120 (every frame of a clip but its last), 1, 2, 4 or 8
+// channels (the divisors of a wavefront's 64 lanes), 16-byte aligned PCM.  Everything else (short frames, 3 / 5 / 6 / 7
+// channels, odd alignments) stays on qoa_decode_frames_kernel above; the plan splits its frame table accordingly
+// (qoa_capi.cpp, DecTables).
 //
-// What bounds it (profiles/r02_*): instruction issue -- the VALU is busy ~85 % of the kernel -- at the ~1.8-2.1 GHz the
-// chip sustains while it also writes ~3.5 TB/s; the memory system itself is not the limit any more (the same kernel
-// with its stores removed runs at 2.2 GHz, a pure fill at 2.5 GHz reaches 5.7-6 TB/s).  Three things got it there:
+// What bounds it (profiles/r03_k2lab_log.md): the MEMORY SKELETON.  The same kernel with the sample arithmetic removed
+// (slice loads, stage, flush reads and stores only) takes as long as the whole kernel (1.5 ms on config 3); with the slices
+// served from L2 or the Infinity Cache it takes 0.95-1.05 ms (the rate of a pure fill of the 5.4 GB), i.e. the 1.1 GB of
+// HBM reads mixed into the store stream cost 0.3-0.5 ms whatever their granularity (64 / 128 bytes per frame and request),
+// alignment, depth of prefetch (one or two units ahead) or cache policy.  The 11.4 VALU per sample are hidden behind it:
+// a row with 13 % fewer VALU (16-byte table entries + v_mad_i64_i32) measured the same time.  Three things got it here:
 //
 //  * Whole-line stores.  A ROUND is 16/NCH slice rows of every frame of the wave: exactly 128 bytes of slices in and
 //    640 bytes = 5 whole 128-byte lines of PCM out per frame.  Lanes scatter their samples into a per-frame LDS RING;
 //    after each phase of PR rows the wave stores the lines that are complete (8 consecutive lanes = one aligned line of
-//    one frame, NLS = FPW/8 store instructions per line), the odd part of a phase stays in the ring for the next one.
-//    The old kernel's 320-byte pieces made every second store a half line: 4.4 vs 5.7 TB/s in tools/ubench/membench.
-//  * Coalesced slice loads.  One 8-byte load per lane per row touched 32 different cache lines per instruction and,
-//    queued behind the CU's own stores, cost 0.6 ms.  Now the wave fetches a staging UNIT (HR rows = 64 bytes per
-//    frame) with 16-byte-per-lane loads, 4 consecutive lanes per frame, one unit ahead, into AccVGPRs -- registers
-//    hipcc never allocates in this kernel, so a load in flight cannot be broken by a compiler-made copy
-//    (tests/test_k2_disasm.py checks that nothing else touches them) -- parks them in an LDS stage at the unit top and
-//    every lane reads its own 8-byte slices back from there.  vmcnt waits are exact and static: behind a unit's loads
-//    there are only the stores of the unit before (K2uCfg::unit_stores).
-//  * The row as ONE generated asm statement (qoa_decode_asm.inc, tools/gen_decode_asm.py): 10 VALU per sample + 1.5 for
+//    one frame, NLS = FPW/8 store instructions per line; one ds_read_b128 per lane and line), the odd part of a phase
+//    stays in the ring for the next one.  The old kernel's 320-byte pieces made every second store a half line: 4.4 vs
+//    5.7 TB/s in tools/ubench/membench.
+//  * Coalesced, asynchronous slice loads.  One 8-byte load per lane per row touched 32 different cache lines per
+//    instruction and, queued behind the CU's own stores, cost 0.6 ms.  Now the wave fetches a staging UNIT (HR rows = 64
+//    bytes per frame) with 16-byte-per-lane LDS-DMA loads (global_load_lds_dwordx4), 4 consecutive lanes per frame, one
+//    unit ahead, straight into its LDS stage; every lane reads its own 8-byte slices back from there at the unit top.  No
+//    register holds a load in flight (round 2 parked them in AccVGPRs).  vmcnt waits are exact and static: behind a unit's
+//    loads there are only the stores of the unit before (K2uCfg::behind).
+//  * The row as ONE generated asm statement (qoa_decode_asm.inc, tools/gen_decode_asm.py): 9 VALU per sample + 1.5 for
 //    the lookups in a PAIR table (two codes per LDS read, both weight steps from one packed shift); hipcc's version of
 //    the same row spends 14.4.  Its range guard (see the generator) keeps a running lower bound of 32767 - max|w|
 //    instead of recomputing it every row; a row it cannot prove exact executes nothing and reports flag = 1, the caller
 //    then checks exactly and either re-enters or takes the 32-bit step (rolled loop, cold).
-// LDS: 8.3 KB ring + 2.3 KB stage per wave (stereo), 16.6 + 2.6 KB (mono), + 4.8 KB of tables per block
-// -> 4-wave blocks, 12 (stereo) / 8 (mono) waves per CU.  K2uCfg and the generated rows cover 1, 2, 4 and 8 channels (the
-// divisors of a wavefront's 64 lanes; at 4 and 8 channels a round is a single staging unit and a single phase of 640 bytes):
-// 8 channels 1.69 -> 1.42 ms, 4 channels 0.91 -> 0.76-0.81 ms on 512 clips x 128 frames against the general kernel.
+// LDS: 8.7 KB ring + 2 KB stage per wave (stereo), 16.6 + 2 KB (mono), + 4.3 KB of tables per block
+// -> 4-wave blocks, 12 (stereo) / 8 (mono) waves per CU.  At 4 and 8 channels a round is a single staging unit and a single
+// phase of 640 bytes.
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
 struct K2uCfg {
@@ -460,8 +463,6 @@ struct K2uCfg {
         return (PB + carry + 127) / 128 * 128;
     }
     static constexpr int RING = ring();
-    static constexpr bool QUAD = NCH == 1 ? QOA_DEC_ROW_QUAD_1 : NCH == 2 ? QOA_DEC_ROW_QUAD_2 : NCH == 4 ? QOA_DEC_ROW_QUAD_4
-                                                                                                 : QOA_DEC_ROW_QUAD_8;
     // Ring stride per frame.  Mono: an odd number of dwords -- 32 frames of a half-wave scatter into 32 different banks.
     // Otherwise RING + 16: the flush reads whole 16-byte pieces with ONE ds_read_b128 each (4 x ds_read_b32 before), and the
     // 2-byte scatter of a half-wave (at most 16 frames, stride 17 or 41 sixteen-byte units) meets at most 2 frames per bank,
@@ -478,9 +479,8 @@ struct K2uCfg {
 #else
     static constexpr int NSLOT = 1;
 #endif
-    // waves per block: the quad form's 16 KB table wants to be shared by as many waves as the CU holds (multiples of 4 only:
-    // other counts load the four SIMDs unevenly -- profiles/r02_k2lab_log.md, run 20)
-    static constexpr int WPB = !QUAD ? 4 : NCH == 8 ? 16 : NCH == 4 ? 8 : 12;
+    // waves per block (multiples of 4 only: other counts load the four SIMDs unevenly -- profiles/r02_k2lab_log.md, run 20)
+    static constexpr int WPB = 4;
     // vector-memory operations younger than unit n's loads at the top of unit n (steady state): the loads of the NSLOT - 1
     // units requested since, and the stores of the NSLOT units since
     static constexpr int behind(int u) {
@@ -519,25 +519,17 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     typedef K2uCfg<NCH> C;
     constexpr int FPW = C::FPW, RR = C::RR, HR = C::HR, PR = C::PR, RING = C::RING, GSP = C::GSP, NLS = C::NLS, NLD = C::NLD,
                   SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = FPW * SSP;
-    constexpr bool QUAD = C::QUAD;
     __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + (NCH == 1 ? 12 : 16)];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][NSLOT * SLOT];
     __shared__ uint2 s_mags[16];
-    // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16, or in the
-    // quad form {deq(a) >> 4 (16 bits, zero-extended), deq(a), deq(b) >> 4, deq(b)} (gen_decode_asm.py)
-    __shared__ __attribute__((aligned(256))) unsigned s_deq2[16][QUAD ? 256 : 64];
+    // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
+    __shared__ __attribute__((aligned(256))) unsigned s_deq2[16][64];
     __shared__ int s_grow[16]; // 20 * ceil(mag3(sf) / 16): the most one row can move a weight
     for (unsigned t = threadIdx.x; t < 1024; t += blockDim.x) {
         const unsigned sf = t >> 6, a = (t >> 3) & 7u, b = t & 7u;
         const int da = (a & 1u) ? -c_mags[sf][a >> 1] : c_mags[sf][a >> 1]; // QOA_DEQUANT_TAB, src/lib.rs:847-864
         const int db = (b & 1u) ? -c_mags[sf][b >> 1] : c_mags[sf][b >> 1];
-        if constexpr (QUAD) {
-            unsigned *e = &s_deq2[sf][(t & 63u) * 4];
-            e[0] = (unsigned)(da >> 4) & 0xffffu; e[1] = (unsigned)da; // the weight step of src/lib.rs:822 beside the value
-            e[2] = (unsigned)(db >> 4) & 0xffffu; e[3] = (unsigned)db;
-        } else {
-            s_deq2[sf][t & 63u] = ((unsigned)da & 0xffffu) | ((unsigned)db << 16);
-        }
+        s_deq2[sf][t & 63u] = ((unsigned)da & 0xffffu) | ((unsigned)db << 16);
     }
     if (threadIdx.x < 16) s_grow[threadIdx.x] = 20 * ((c_mags[threadIdx.x][3] + 15) >> 4);
     init_mag_table(s_mags); // (ends with the block barrier)
@@ -610,13 +602,6 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     const unsigned img_lds = (unsigned)(size_t)(lds_ptr)img + my_img;
     int slack = dec_slack(pk);
     (void)tab_lds; (void)grow_lds; (void)img_lds; (void)slack;
-#ifdef QOA_K2U_LAB_PREFETCH
-    const unsigned long long pf_base = (unsigned long long)(in + frames[frame0].frame_off + 8 + 16 * NCH); // frames assumed consecutive
-    for (unsigned j = 0; j < (unsigned)FPW; j++) {
-        const unsigned long long a = pf_base + j * (8 + 16 * NCH + 2048 * NCH) + lane * 16;
-        asm volatile("global_load_dwordx4 a[0:3], %0, off" : : "v"(a) : "memory", "a0", "a1", "a2", "a3");
-    }
-#endif
     constexpr unsigned kRounds = 256 / RR, kUnits = kRounds * UNITS;
     static_assert(kUnits > 2 * NSLOT, "staging depth");
     // unit top (n = the unit's number in the frame): its slices have landed in slot n % NSLOT -- behind them in the vmcnt
@@ -628,15 +613,6 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         if (n < (unsigned)NSLOT || n + NSLOT > kUnits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(C::behind(u)) : "memory");
         const unsigned slot_off = NSLOT == 1 ? 0u : (n % NSLOT) * SLOT;
-#ifdef QOA_K2U_LAB_PREFETCH // lab: every 1 KB of a frame's slices is pulled towards L2/MALL in ONE contiguous read, a quarter frame ahead
-        if ((n * CB) % 1024 == 0 && (n * CB) / 1024 + 1 < 2 * NCH) {
-            const unsigned long long q0 = pf_base + ((n * CB) / 1024 + 1) * 1024 + lane * 16;
-            for (unsigned j = 0; j < (unsigned)FPW; j++) {
-                const unsigned long long a = q0 + j * (8 + 16 * NCH + 2048 * NCH);
-                asm volatile("global_load_dwordx4 a[0:3], %0, off" : : "v"(a) : "memory", "a0", "a1", "a2", "a3");
-            }
-        }
-#endif
 #pragma unroll
         for (int r = 0; r < HR; r++) unit_raw[r] = *(const uint2 *)(stage + slot_off + my_stage + r * NCH * 8);
         if (n + NSLOT < kUnits) {
@@ -669,8 +645,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                      : [w01] "+v"(pk.w01), [w23] "+v"(pk.w23), [pa] "+v"(pk.pa), [pm] "+v"(pk.pm), [pb] "+v"(pk.pb),   \
                        [sa] "+v"(pk.sa), [sm] "+v"(pk.sm), [sb] "+v"(pk.sb), [slack] "+v"(slack), [flag] "=s"(flag)    \
                      : [rx] "v"(raw.x), [ry] "v"(raw.y), [tab] "s"(tab_lds), [grow] "s"(grow_lds), [img] "v"(img_lds),  \
-                       [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [k19] "s"(0x80000), [force] "s"(force)       \
-                     : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS_##N);
+                       [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [force] "s"(force)                            \
+                     : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS);
                     QOA_DEC_ROW_CASE(8, 0) QOA_DEC_ROW_CASE(8, 1)
                     QOA_DEC_ROW_CASE(4, 0) QOA_DEC_ROW_CASE(4, 1) QOA_DEC_ROW_CASE(4, 2) QOA_DEC_ROW_CASE(4, 3)
                     QOA_DEC_ROW_CASE(2, 0) QOA_DEC_ROW_CASE(2, 1) QOA_DEC_ROW_CASE(2, 2) QOA_DEC_ROW_CASE(2, 3)
@@ -776,17 +752,15 @@ static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const
     constexpr unsigned W = QOA_K2U_WPB_OVERRIDE ? QOA_K2U_WPB_OVERRIDE : K2uCfg<NCH>::WPB;
     const unsigned waves = n_frames / FPW; // the plan only puts whole wavefronts of frames into this table
     if (waves * FPW != n_frames) return hipErrorInvalidValue;
-    // ONE launch: the last block may be short of waves (they leave behind the table barrier).  A second, small launch for the
-    // remainder would run after the first on the stream, alone on the chip, for as long as a full wave takes: +0.25 ms.
-    // Block size by how far the work fills the chip: big blocks (one table for W waves) only when every CU gets one.
-    auto go = [&](auto wc) {
-        constexpr unsigned w = decltype(wc)::value;
-        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, w>), dim3((waves + w - 1) / w), dim3(64 * w), 0, stream, in, out,
+    // ONE launch: the last block may be short of waves (they leave behind the table barrier).  A second, small launch for a
+    // remainder runs after the first on the stream, alone on the chip, for as long as a full wave takes (+0.25 ms measured).
+    // Work that does not give every CU a block (single clips) runs one wavefront per block, spread over the CUs.
+    if (waves >= 256u * W)
+        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, W>), dim3((waves + W - 1) / W), dim3(64 * W), 0, stream, in, out,
                            frames, n_frames, mismatches);
-    };
-    if (waves >= 256u * W) go(std::integral_constant<unsigned, W>{});
-    else if (waves >= 256u * 4u) go(std::integral_constant<unsigned, 4>{});
-    else go(std::integral_constant<unsigned, 1>{});
+    else
+        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, 1>), dim3(waves), dim3(64), 0, stream, in, out, frames, n_frames,
+                           mismatches);
     return hipGetLastError();
 }
 

@@ -2,15 +2,23 @@
 
 K2 and K2u fetch their slices with asynchronous global loads whose results are consumed rows later.  If the
 destination were an ordinary asm output, hipcc would be free to copy or spill it between the load and its wait -- it
-believes the value is there when the asm statement ends -- and the kernel would decode garbage without any error.  The
-loads therefore target AccVGPRs, which hipcc does not allocate in these kernels, and only the statement that has
-waited for them moves them on.  This test pins that discipline down on the binary that ships:
+believes the value is there when the asm statement ends -- and the kernel would decode garbage without any error.
 
-  * the only instructions that touch an AccVGPR are the slice loads (destination), `v_accvgpr_read_b32` and
-    `ds_write2_b64` (source);
-  * every one of those readers is preceded, in its basic block, by an `s_waitcnt vmcnt(..)` with no slice load in
-    between -- it cannot observe a load that is still in flight;
-  * no scratch (spill) instructions exist in the decode kernels.
+K2 (general kernel): the loads target AccVGPRs, which hipcc does not allocate in these kernels, and only the statement that
+has waited for them moves them on.  Pinned down on the binary that ships:
+  * the only instructions that touch an AccVGPR are the slice loads (destination) and `v_accvgpr_read_b32` (source);
+  * every reader is preceded, in its basic block, by an `s_waitcnt vmcnt(..)` with no slice load in between.
+
+K2u (uniform kernel, round 3): the loads are LDS-DMA (`global_load_lds_dwordx4`): no register holds a load in flight and
+the kernel uses no AccVGPR at all.  What must hold instead:
+  * M0 (the DMA's LDS destination) is written in the two instructions before every DMA load;
+  * WAR: between the last ordinary LDS read and a DMA load there is an `s_waitcnt lgkmcnt(0)` (the stage slot is being
+    overwritten: the reads of its old contents must have returned);
+    (The RAW side -- the stage is read only behind the unit top's `s_waitcnt vmcnt` -- is by construction in `unit_top` and
+    covered by the bit-exact GPU tests: in a disassembly the stage reads cannot be told from the cold path's table reads,
+    and the loop's layout order is not its execution order.)
+
+No scratch (spill) instructions exist in any decode kernel.
 """
 import os
 import re
@@ -84,11 +92,14 @@ def kernels(tmp_path_factory):
 def test_accvgprs_are_touched_only_by_the_prefetch_protocol(kernels):
     checked = 0
     for name, ins in kernels.items():
+        if "qoa_decode_uniform_kernel" in name:
+            assert not any(ACC.search(i.split(None, 1)[1]) for i in ins if " " in i), name  # K2u: no AccVGPR at all
+            continue
         for i in ins:
             if not ACC.search(i.split(None, 1)[1] if " " in i else ""):
                 continue
             op = i.split()[0]
-            assert op in ("global_load_dwordx2", "global_load_dwordx4", "v_accvgpr_read_b32", "ds_write2_b64"), (name, i)
+            assert op in ("global_load_dwordx2", "v_accvgpr_read_b32"), (name, i)
             if op.startswith("global_load"):
                 assert ACC.match(i.split(None, 1)[1]), (name, i)  # AccVGPR is the destination
             checked += 1
@@ -106,8 +117,38 @@ def test_prefetched_slices_are_read_only_behind_a_wait(kernels):
                 waited = True
             if op.startswith("global_load") and ACC.match(i.split(None, 1)[1]):
                 waited = False
-            if op in ("v_accvgpr_read_b32", "ds_write2_b64") and ACC.search(i.split(None, 1)[1]):
+            if op == "v_accvgpr_read_b32" and ACC.search(i.split(None, 1)[1]):
                 assert waited, (name, i)
+
+
+def test_k2u_lds_dma_protocol(kernels):
+    """The uniform kernels' slice loads: LDS-DMA with M0 set right before, lgkmcnt(0) between the last LDS read and the DMA that
+    overwrites the stage."""
+    seen = 0
+    for name, ins in kernels.items():
+        if "qoa_decode_uniform_kernel" not in name:
+            continue
+        lds_read_pending = False   # an LDS read issued, no lgkmcnt(0) since
+        dma_unwaited = False       # a DMA load issued, no vmcnt wait since
+        n_dma = n_stage = 0
+        for k, i in enumerate(ins):
+            op = i.split()[0]
+            if op == "s_waitcnt":
+                if "lgkmcnt(0)" in i:
+                    lds_read_pending = False
+                if "vmcnt" in i:
+                    dma_unwaited = False
+            elif op.startswith("ds_read"):
+                lds_read_pending = True
+                n_stage += 1
+            elif op == "global_load_lds_dwordx4":
+                assert not lds_read_pending, (name, k, i)
+                assert any(re.match(r"s_mov_b32 m0, s\d+", p) for p in ins[k - 2:k]), (name, ins[k - 3:k + 1])
+                dma_unwaited = True
+                n_dma += 1
+        assert n_dma >= 2 and n_stage >= 1, (name, n_dma, n_stage)
+        seen += 1
+    assert seen >= 8  # 1 / 2 / 4 / 8 channels x the block sizes
 
 
 def test_decode_kernels_do_not_spill(kernels):

@@ -42,20 +42,6 @@ HI, LO, TAB, T, G = 84, 85, 86, 87, 88
 P, U, RC0, RC1, RT, ST = 89, 90, 91, 92, 93, 94   # RT / ST: the fourth ring slots
 CLOBBERS = list(range(64, 95))
 
-# ---- the "quad" form (2, 4 and 8 channels) -------------------------------------------------------------------------------
-# The pair table holds 16-byte entries [sf][code a * 8 + code b] = {da, deq(a), db, deq(b)}: deq as a sign-extended dword,
-# d = deq >> 4 (the weight step of src/lib.rs:822) as a zero-extended 16-bit image.  One ds_read_b128 lands a pair's entry in
-# four consecutive registers v[4j : 4j+3], and
-#     u = (p >> 13) + deq        is ONE   v_mad_i64_i32 v[q:q+1], vcc, p, 2^19, v[q:q+1]
-# -- the 64-bit sum p * 2^19 + (deq : d) has (p >> 13) + deq in its high dword exactly: the low dword (p & 0x1fff) << 19 plus
-# d < 2^16 cannot carry -- so the shift, the add and the packed shift that formed the weight steps are gone: 8 VALU per sample
-# + 1 for the lookups (6 bits -> address) instead of 9 + 1.5.  Exact for every p, also a wrapped one (src/lib.rs:799-805
-# wraps in i32 before the shift; p IS that wrapped sum).  Price: a 16 KB table per block and 128-bit table reads.
-QE0 = 64                     # v64..v103: ten entries of four dwords
-QHI, QLO, QTAB, QT, QG, QP, QH3, QRT, QST = 104, 105, 106, 107, 108, 109, 110, 111, 112
-QCLOBBERS = list(range(64, 113))
-
-
 def ring(kind):
     if kind == "P":
         return ["%[pb]", f"v{RT}", "%[pa]", "%[pm]"]
@@ -113,92 +99,6 @@ def step(i, nch, row, ring_bytes):
     else:
         off = ((row * 20 + i) * nch * 2) % ring_bytes
         L.append(f"ds_write_b16_d16_hi %[img], {Bn} offset:{off}")   # the new sample is the pair's high half
-    return L
-
-
-def q_extraction():
-    L = []
-    for j in range(10):
-        p = 54 - 6 * j
-        e = f"v{QE0 + 4 * j}"
-        if p >= 32:
-            L.append(f"v_bfe_u32 {e}, v{QHI}, {p - 32}, 6")
-        elif p + 5 < 32:
-            L.append(f"v_bfe_u32 {e}, v{QLO}, {p}, 6")
-        else:  # the pair that straddles the two words
-            L.append(f"v_alignbit_b32 {e}, v{QHI}, v{QLO}, {p}")
-            L.append(f"v_and_b32 {e}, 63, {e}")
-        L.append(f"v_lshl_add_u32 {e}, {e}, 4, v{QTAB}")
-        L.append(f"ds_read_b128 v[{QE0 + 4 * j}:{QE0 + 4 * j + 3}], {e}")
-    return L
-
-
-def q_ring(kind):
-    if kind == "P":
-        return ["%[pb]", f"v{QRT}", "%[pa]", "%[pm]"]
-    return ["%[sb]", f"v{QST}", "%[sa]", "%[sm]"]
-
-
-def q_step(i, nch, row, ring_bytes):
-    R, S = q_ring("P"), q_ring("S")
-    A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
-    SA, SB = S[(i + 2) % 4], S[i % 4]
-    q = QE0 + 4 * (i // 2) + 2 * (i % 2)      # (d, deq) of this sample; u replaces deq
-    d, u = f"v{q}", f"v{q + 1}"
-    uprev = f"v{QH3}" if i == 0 else f"v{QE0 + 4 * ((i - 1) // 2) + 2 * ((i - 1) % 2) + 1}"
-    bcast = "op_sel:[0,0,0] op_sel_hi:[0,1,1]"   # d's low half into both lanes of src0
-    L = [
-        f"v_dot2_i32_i16 v{QP}, %[w01], {A}, 0",
-        f"v_dot2_i32_i16 v{QP}, %[w23], {B}, v{QP}",
-        f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",       # the inline 15 has no high half to select
-        f"v_pk_mad_u16 %[w01], {d}, {SA}, %[w01] {bcast}",
-        f"v_or_b32 {SB}, %[one2], {SB}",                           # (+-1, +-1) for B
-        f"v_pk_mad_u16 %[w23], {d}, {SB}, %[w23] {bcast}",
-        f"v_mad_i64_i32 v[{q}:{q + 1}], vcc, v{QP}, %[k19], v[{q}:{q + 1}]",   # u = (p >> 13) + deq (high dword)
-        f"v_cvt_pk_i16_i32 {Bn}, {uprev}, {u}",                   # (h3, recon), both clamped
-    ]
-    off = ((row * 20 + i) * nch * 2) % ring_bytes
-    L.append(f"ds_write_b16_d16_hi %[img], {Bn} offset:{off}")   # the new sample is the pair's high half
-    return L
-
-
-def q_row_text(nch, row, ring_bytes):
-    L = [
-        f"v_perm_b32 v{QHI}, %[rx], %[rx], %[bsw]",
-        f"v_perm_b32 v{QLO}, %[ry], %[ry], %[bsw]",
-        f"v_lshrrev_b32 v{QT}, 28, v{QHI}",
-        f"v_lshl_add_u32 v{QTAB}, v{QT}, 10, %[tab]",              # &s_deq4[sf][0]: 64 entries of 16 bytes
-        f"v_lshl_add_u32 v{QT}, v{QT}, 2, %[grow]",
-        f"ds_read_b32 v{QG}, v{QT}",
-    ]
-    L += q_extraction()
-    L += [
-        "s_cmp_lg_u32 %[force], 0",
-        "s_cbranch_scc1 Lqoa_go_%=",
-        "s_waitcnt lgkmcnt(10)",                      # the 10 table reads are younger than G's
-        f"v_cmp_lt_i32 vcc, %[slack], v{QG}",
-        "s_cbranch_vccnz Lqoa_decline_%=",
-        f"v_sub_u32 %[slack], %[slack], v{QG}",
-        "Lqoa_go_%=:",
-    ]
-    # LDS ops retire in order: the table reads first, then one image write per sample.  Before sample 2k the entries 0..k
-    # must be in: at most 9 - k table reads + the 2k image writes issued so far may be outstanding.
-    L += [f"v_ashrrev_i32 v{QH3}, 16, {q_ring('P')[0]}"]  # h3: sample 0's "reconstruction before"
-    waits = [0, 1, 2, 4, 6, 10]                       # pairs at which the row waits; the last entry is the end marker
-    for i in range(20):
-        if i % 2 == 0 and i // 2 in waits[:-1]:
-            k = i // 2
-            last = waits[waits.index(k) + 1] - 1      # entries k..last must be in: (9 - last) younger reads + 2k image writes
-            L += [f"s_waitcnt lgkmcnt({min(15, (9 - last) + 2 * k)})"]
-        L += q_step(i, nch, row, ring_bytes)
-    L += [
-        "s_mov_b32 %[flag], 0",
-        "s_branch Lqoa_end_%=",
-        "Lqoa_decline_%=:",
-        "s_waitcnt lgkmcnt(0)",                       # the scratch registers are the compiler's again after this statement
-        "s_mov_b32 %[flag], 1",
-        "Lqoa_end_%=:",
-    ]
     return L
 
 
@@ -284,29 +184,20 @@ def emit(name, lines):
 
 # (channels, rows per round, image ring bytes): must agree with K2uCfg in qoa_decode.hip (static_asserts there)
 GEOMETRY = {1: (16, 256), 2: (8, 256), 4: (4, 640), 8: (2, 640)}
-# row form per channel count: "pair" = 4-byte pair-table entries (9 + 1.5 VALU per sample), "quad" = 16-byte entries + the
-# one-instruction shift-and-add (8 + 1).  Mono keeps "pair": its 64 frame rings per wavefront leave no LDS for a 16 KB table.
-FORMS = {1: "pair", 2: "quad", 4: "quad", 8: "quad"}
 
 
-def render(forms=None):
-    forms = {**FORMS, **(forms or {})}
+def render():
     out = ["// GENERATED by tools/gen_decode_asm.py -- do not edit.",
            "// QOA_DEC_ROW_TEXT_<channels>_<row of the round>: one slice row of K2u (20 samples of every chain of the wave) on",
-           "// i16-packed weights / history.  QOA_DEC_ROW_QUAD_<channels>: 1 = 16-byte pair-table entries {d, deq, d, deq} and",
-           "// v_mad_i64_i32 for (p >> 13) + deq (scratch v64-v112), 0 = 4-byte entries (scratch v64-v94).  See the generator.",
-           ]
-    for n in GEOMETRY:
-        regs = QCLOBBERS if forms[n] == "quad" else CLOBBERS
-        out.append(f"#define QOA_DEC_ROW_CLOBBERS_{n} " + ", ".join(f'"v{r}"' for r in regs))
-        out.append(f"#define QOA_DEC_ROW_QUAD_{n} {1 if forms[n] == 'quad' else 0}")
-    out += ["#define QOA_DEC_ASM_RING_%d %d" % (n, GEOMETRY[n][1]) for n in GEOMETRY] + [""]
-    n_lines = {}
+           "// i16-packed weights / history; scratch v64-v94.  See the generator for operands and wait-state rules.",
+           f"#define QOA_DEC_ROW_CLOBBERS " + ", ".join(f'"v{r}"' for r in CLOBBERS),
+           ] + ["#define QOA_DEC_ASM_RING_%d %d" % (n, GEOMETRY[n][1]) for n in GEOMETRY] + [""]
+    n_lines = 0
     for nch, (rows, ring_bytes) in GEOMETRY.items():
         for row in range(rows):
-            t = (q_row_text if forms[nch] == "quad" else row_text)(nch, row, ring_bytes)
+            t = row_text(nch, row, ring_bytes)
             check_hazards(t)
-            n_lines[nch] = len(t)
+            n_lines = len(t)
             out.append(emit(f"QOA_DEC_ROW_TEXT_{nch}_{row}", t))
     return "\n".join(out), n_lines
 
@@ -315,23 +206,10 @@ INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaud
 
 
 def main():
-    # usage: gen_decode_asm.py [--out PATH] [--forms 2:pair,4:quad,...]   (the lab builds alternative forms side by side)
-    path, forms = INC_PATH, {}
-    args = sys.argv[1:]
-    while args:
-        a = args.pop(0)
-        if a == "--out":
-            path = args.pop(0)
-        elif a == "--forms":
-            for item in args.pop(0).split(","):
-                n, f = item.split(":")
-                forms[int(n)] = f
-        else:
-            raise SystemExit(f"unknown argument {a}")
-    out, n = render(forms)
-    with open(path, "w") as f:
+    out, n = render()
+    with open(INC_PATH, "w") as f:
         f.write(out)
-    print(f"wrote {path}: lines per row {n}")
+    print(f"wrote {INC_PATH}: {n} lines per row")
 
 
 if __name__ == "__main__":
