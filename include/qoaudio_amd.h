@@ -135,6 +135,8 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_LDS_TABLES 8u         /* debug: quantiser / dequantiser looked up in an LDS table in every launch (same bytes; */
 #define QOA_PLAN_NO_LDS_TABLES 128u    /*        default: only in launches with >= 8 wavefronts per SIMD) / in none */
 #define QOA_PLAN_EXACT_QUOTIENT 256u   /* debug: speculative steps always with the exact qoa_div fix-up (same bytes) */
+#define QOA_PLAN_COUNTERS 512u         /* count the fast paths' fall-backs (qoa_encode_plan_stats / _counters); without it the */
+                                       /* kernel is handed no counter block and executes no atomic at all */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
 #define QOA_PLAN_CPW_2 (2u << 4)
 #define QOA_PLAN_CPW_4 (4u << 4)
@@ -145,10 +147,17 @@ void qoa_encode_plan_free(qoa_encode_plan *plan);
 /* Bytes the batch reads / writes (algorithmic bytes of one run). */
 int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint64_t *out_bytes,
                           uint64_t *samples_i16);
+/* How the plan's launches are shaped (diagnostics for bench.py): total wavefronts over its launches, chains per wavefront
+ * of the largest launch, and whether that launch takes the LDS-table step form (chosen from 8 wavefronts per SIMD up, or
+ * forced by QOA_PLAN_LDS_TABLES).  Any pointer may be null. */
+int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
+                                uint32_t *lds_table_form);
 /* Enqueue the encode of the whole batch on `stream` (a hipStream_t, may be NULL).  d_pcm and
  * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
 int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);
-/* Diagnostics of the plan's runs so far (synchronises the device); none of this affects the bytes produced.
+/* Diagnostics of the plan's runs so far (synchronises the device); none of this affects the bytes produced.  Only plans
+ * created with QOA_PLAN_COUNTERS count; for any other plan both calls return the IoError code (detail: "plan was created
+ * without QOA_PLAN_COUNTERS").
  *   *declined_slices    (chain, slice) pairs for which the kernel's i16-packed path could not prove its result exact
  *                       and the 32-bit path evaluated the slice again;
  *   *unpacked_slices    full slices that went straight to the 32-bit path because a chain's LMS state was outside the
@@ -195,6 +204,34 @@ int qoa_host_pipeline_decode(qoa_host_pipeline *p, const qoa_clip *clips, size_t
 int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc, int16_t *h_pcm,
                           uint32_t chunk_frames);
 
+/* ---- multi-GPU batches in ONE process (BASELINE config 4; no counterpart in the reference, which is
+ * single-threaded: what a Rust host would call per clip is encode_all, src/lib.rs:760-763) ----
+ * devices[0 .. n_devices) are HIP device ordinals; devices[0] is the ROOT.  Clips are independent, so the batch is cut into
+ * n_devices contiguous shards -- qoa_multi_shard gives shard i's [first, first + count): the first n_clips % n_devices
+ * shards hold one clip more -- and device i encodes / decodes shard i with its own host thread, streams and time-sliced
+ * pipeline (qoa_host_pipeline_*), with no collective on the data path.
+ *   encode: pcm[i] is the base of shard i's PCM -- host memory, or memory of devices[i] -- and the shard's clips'
+ *           pcm_offset count from it; `out` is ONE destination for the whole batch, host memory or memory of the root, and
+ *           every out_offset counts from it.  A shard's encoded bytes travel to `out` slice by slice while the next slice
+ *           is being encoded (peer copies over xGMI when `out` is on the root): that IS the gather of the encoded streams.
+ *   decode: `enc` is ONE source (host or root memory, out_offset counts from it), pcm[i] the destination base of shard i.
+ * Memory of any other device is legal wherever the HIP runtime can copy from / to it.  Synchronous: complete on return.
+ * Errors: a device ordinal that does not exist or is listed twice, and every HIP failure (peer access included), return
+ * the IoError code with qoa_last_error_detail() naming the device; nothing aborts. */
+typedef struct qoa_multi qoa_multi;
+int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out);
+void qoa_multi_free(qoa_multi *m);
+int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t *first, size_t *count);
+int qoa_multi_encode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const int16_t *const *pcm, uint8_t *out,
+                     uint32_t chunk_frames);
+int qoa_multi_decode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const uint8_t *enc, int16_t *const *pcm,
+                     uint32_t chunk_frames);
+/* one-shot forms (the handle lives for the call) */
+int qoa_encode_batch_multi(const int *devices, int n_devices, const qoa_clip *clips, size_t n_clips,
+                           const int16_t *const *pcm, uint8_t *out, uint32_t chunk_frames);
+int qoa_decode_batch_multi(const int *devices, int n_devices, const qoa_clip *clips, size_t n_clips, const uint8_t *enc,
+                           int16_t *const *pcm, uint32_t chunk_frames);
+
 /* ================================================================== decoder */
 
 /* FrameHeader, src/lib.rs:774-781 */
@@ -228,6 +265,15 @@ typedef struct qoa_decoder qoa_decoder;
  * io::Read cannot cross a C ABI: the host shim reads the bytes, the GPU decodes whole frames and
  * the iterator drains the decoded PCM in the reference's exact item order. */
 int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **out);
+/* QoaDecoder::new over a LAZY reader, src/lib.rs:117-169 with `R: io::Read`: `read` fills buf with up to len bytes and
+ * returns how many it stored -- 0 at the end of the stream, a negative value for an I/O error of the caller's reader
+ * (reported as IoError; short reads are retried as read_exact does, :124-126).  new() pulls the 8 header bytes and, in
+ * fixed mode, the first frame (the reference parses its header + LMS block inside new(), :161-166); every later frame is
+ * pulled -- its 8-byte header, then the LMS block and slice rows that header announces -- only when qoa_decoder_next has
+ * handed out the last sample of the frame before (:679-685).  The reference issues the same reads slice row by slice row;
+ * here the reader is at most one frame ahead of the items.  `ctx` must stay valid until qoa_decoder_free. */
+typedef int64_t (*qoa_read_fn)(void *ctx, uint8_t *buf, size_t len);
+int qoa_decoder_new_reader(qoa_read_fn read, void *ctx, qoa_decoder **out);
 /* QoaDecoder::new_streaming, src/lib.rs:632-638 */
 int qoa_decoder_new_streaming(qoa_decoder **out);
 void qoa_decoder_free(qoa_decoder *dec);

@@ -1,6 +1,9 @@
 """CPU baseline legs of bench.py, run in a process that never touches the GPU.
 
-    python -m oracle.cpu_bench <clips.npy> <sample_rate> <budget_seconds> [--no-all-cores]
+    python -m oracle.cpu_bench <clips.npy> <sample_rate> <budget_seconds> [--no-all-cores] [--no-digests]
+
+QOA_ORACLE_LIB=liboracle_native.so in the environment times the -march=native build instead (rebuilt first when
+`--rebuild` is given: -march=native must be compiled on the machine it runs on).
 
 TEST INFRASTRUCTURE ONLY (see oracle/README.md).  bench.py copies a bounded sample of the very clips the GPU
 encoded to a .npy file and starts this module as a child process; the child times the oracle's ref_style encoder
@@ -32,6 +35,11 @@ def main(argv):
     path, _RATE, budget = argv[0], int(argv[1]), float(argv[2])
     all_cores = "--no-all-cores" not in argv
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if "--rebuild" in argv:
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        name = os.environ.get("QOA_ORACLE_LIB", "liboracle.so")
+        subprocess.check_call(["make", "-s", "-B", "-C", here, name])
     from oracle import oracle as O
     O.lib()
     _CLIPS = np.load(path, mmap_mode="r")  # [n, samples, channels] int16

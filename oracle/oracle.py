@@ -61,10 +61,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        # QOA_ORACLE_LIB=liboracle_native.so selects the -march=native build (oracle/cpu_bench.py's second leg)
+        name = os.environ.get("QOA_ORACLE_LIB", "liboracle.so")
+        path = os.path.join(_HERE, name)
         src = os.path.join(_HERE, "qoa_oracle.c")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            build()
+            subprocess.check_call(["make", "-s", "-C", _HERE, name])
         L = C.CDLL(path)
         L.oq_encoded_size.restype = C.c_size_t
         L.oq_encoded_size.argtypes = [C.c_uint32, C.c_uint32]

@@ -17,10 +17,12 @@ SYMBOLS = [
     "qoa_encoded_size", "qoa_frame_size",
     "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
     "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_encode_all",
-    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
+    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_launch_info", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
     "qoa_encode_batch_host", "qoa_host_pipeline_create", "qoa_host_pipeline_free", "qoa_host_pipeline_encode",
     "qoa_host_pipeline_decode", "qoa_decode_batch_host",
-    "qoa_decoder_new", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
+    "qoa_multi_create", "qoa_multi_free", "qoa_multi_shard", "qoa_multi_encode", "qoa_multi_decode",
+    "qoa_encode_batch_multi", "qoa_decode_batch_multi",
+    "qoa_decoder_new", "qoa_decoder_new_reader", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
     "qoa_decoder_current_frame_header", "qoa_decoder_total_duration", "qoa_decoder_next",
     "qoa_decoder_read_samples", "qoa_decoder_decode_frame", "qoa_decode_all",
     "qoa_stream_scan", "qoa_decode_plan_from_streams", "qoa_decode_plan_from_clips", "qoa_decode_plan_free",
@@ -51,6 +53,10 @@ class StreamInfo(C.Structure):
 
 class Item(C.Structure):
     _fields_ = [("kind", C.c_int), ("sample", C.c_int16), ("header", FrameHeader), ("error", C.c_int)]
+
+
+# qoa_read_fn: int64_t (*)(void *ctx, uint8_t *buf, size_t len)
+READ_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 
 
 def build(force=False):
@@ -106,6 +112,7 @@ def lib():
     L.qoa_encode_plan_free.restype = None
     L.qoa_encode_plan_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_run.argtypes = [vp, vp, vp, vp]
+    L.qoa_encode_plan_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.qoa_encode_plan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_counters.argtypes = [vp, C.POINTER(C.c_uint64), sz]
     L.qoa_encode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]
@@ -115,7 +122,17 @@ def lib():
     L.qoa_host_pipeline_free.restype = None
     L.qoa_host_pipeline_encode.argtypes = [vp, C.POINTER(Clip), sz, vp, vp, C.c_uint32]
     L.qoa_host_pipeline_decode.argtypes = [vp, C.POINTER(Clip), sz, vp, vp, C.c_uint32]
+    ip = C.POINTER(C.c_int)
+    L.qoa_multi_create.argtypes = [ip, C.c_int, C.POINTER(vp)]
+    L.qoa_multi_free.argtypes = [vp]
+    L.qoa_multi_free.restype = None
+    L.qoa_multi_shard.argtypes = [sz, C.c_int, C.c_int, szp, szp]
+    L.qoa_multi_encode.argtypes = [vp, C.POINTER(Clip), sz, C.POINTER(vp), vp, C.c_uint32]
+    L.qoa_multi_decode.argtypes = [vp, C.POINTER(Clip), sz, vp, C.POINTER(vp), C.c_uint32]
+    L.qoa_encode_batch_multi.argtypes = [ip, C.c_int, C.POINTER(Clip), sz, C.POINTER(vp), vp, C.c_uint32]
+    L.qoa_decode_batch_multi.argtypes = [ip, C.c_int, C.POINTER(Clip), sz, vp, C.POINTER(vp), C.c_uint32]
     L.qoa_decoder_new.argtypes = [vp, sz, C.POINTER(vp)]
+    L.qoa_decoder_new_reader.argtypes = [READ_FN, vp, C.POINTER(vp)]
     L.qoa_decoder_new_streaming.argtypes = [C.POINTER(vp)]
     L.qoa_decoder_free.argtypes = [vp]
     L.qoa_decoder_free.restype = None

@@ -203,17 +203,34 @@ def encode_all(sample_data, desc: QoaDesc) -> bytes:
 
 
 class QoaDecoder:
-    """QoaDecoder<R>, src/lib.rs:59-68, :117-201, :619-693.  `reader` is bytes-like or a file-like object
-    (read fully: the GPU decodes whole frames, the iterator drains them in the reference's item order)."""
+    """QoaDecoder<R>, src/lib.rs:59-68, :117-201, :619-693.  `reader` is bytes-like, or a file-like object that is pulled
+    LAZILY, one frame at a time, as the iterator advances (qoa_decoder_new_reader): the GPU decodes whole frames, the
+    iterator drains them in the reference's item order, and into_inner() hands the reader back where the last pulled
+    frame ended."""
 
     def __init__(self, reader=None, *, _streaming=False):
         self._h = C.c_void_p(None)
+        self._reader = None
         L = _lib.lib()
         if _streaming:
             rc = L.qoa_decoder_new_streaming(C.byref(self._h))
+        elif hasattr(reader, "read"):
+            self._reader = reader
+
+            def _pull(_ctx, buf, n):  # qoa_read_fn: bytes stored, 0 at the end, negative for an I/O error
+                try:
+                    chunk = reader.read(n)
+                except OSError:
+                    return -1
+                if not chunk:
+                    return 0
+                C.memmove(buf, chunk, len(chunk))
+                return len(chunk)
+
+            self._cb = _lib.READ_FN(_pull)  # must outlive the handle
+            rc = L.qoa_decoder_new_reader(self._cb, None, C.byref(self._h))
         else:
-            data = reader.read() if hasattr(reader, "read") else bytes(reader)
-            buf = np.frombuffer(data, dtype=np.uint8)
+            buf = np.frombuffer(bytes(reader), dtype=np.uint8)
             rc = L.qoa_decoder_new(buf.ctypes.data_as(C.c_void_p) if buf.size else None, buf.size, C.byref(self._h))
         if rc:
             self._h = None
@@ -226,8 +243,7 @@ class QoaDecoder:
     def open(cls, path):
         """src/lib.rs:619-625"""
         try:
-            with open(path, "rb") as f:
-                return cls(f.read())
+            return cls(open(path, "rb"))  # io::BufReader<File>: read lazily, src/lib.rs:619-625
         except OSError as e:
             err = DecodeError.__new__(DecodeError)
             Exception.__init__(err, f"IO error: {e}")
@@ -246,6 +262,14 @@ class QoaDecoder:
                 self._h = None
         except Exception:
             pass
+
+    def into_inner(self):
+        """src/lib.rs:172-178: the reader, positioned behind the last frame the decoder pulled from it."""
+        r, self._reader = self._reader, None
+        if getattr(self, "_h", None):
+            _lib.lib().qoa_decoder_free(self._h)
+            self._h = None
+        return r
 
     def mode(self) -> ProcessingMode:
         m = _lib.Mode()

@@ -20,6 +20,7 @@ PLAN_NO_SPECULATION = 4
 PLAN_LDS_TABLES = 8
 PLAN_NO_LDS_TABLES = 128
 PLAN_EXACT_QUOTIENT = 256
+PLAN_COUNTERS = 512  # count the fast paths' fall-backs (EncodePlan.stats / .counters); off by default: no atomics in the kernel
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 
 
@@ -74,6 +75,12 @@ class EncodePlan:
                                             _stream_ptr(stream))
         if rc:
             raise EncodeError(rc)
+
+    def launch_info(self) -> Tuple[int, int, bool]:
+        """(wavefronts over all launches, chains per wavefront of the largest launch, LDS-table step form?)."""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _lib.lib().qoa_encode_plan_launch_info(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, bool(c.value)
 
     def stats(self) -> Tuple[int, int, int]:
         """(declined, unpacked, speculation_misses): slices the kernel's fast paths handed to a slower form, summed over
@@ -248,6 +255,63 @@ class HostPipeline:
         arr = _clips_array(clips)
         rc = _lib.lib().qoa_host_pipeline_decode(self._h, arr, len(clips), C.c_void_p(enc.data_ptr()),
                                                  C.c_void_p(pcm.data_ptr()), chunk_frames)
+        if rc:
+            raise DecodeError(rc)
+
+
+def multi_shard(n_clips: int, n_devices: int, index: int) -> Tuple[int, int]:
+    """(first, count) of shard `index` of the block partition qoa_multi_* uses (= dist.shard_range)."""
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    if _lib.lib().qoa_multi_shard(n_clips, n_devices, index, C.byref(a), C.byref(b)):
+        raise ValueError("bad shard index")
+    return a.value, b.value
+
+
+class MultiGpu:
+    """Several GPUs driven from ONE process through the C ABI (qoa_multi_*): device i encodes / decodes shard i of the
+    clip list with its own host thread and time-sliced pipeline; with `out` on devices[0] the stage-out of every slice is
+    the peer copy that gathers the encoded streams on the root (include/qoaudio_amd.h)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.devices = list(devices)
+        self._h = C.c_void_p(None)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = _lib.lib().qoa_multi_create(arr, len(self.devices), C.byref(self._h))
+        if rc:
+            self._h = None
+            raise EncodeError(rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().qoa_multi_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _bases(self, tensors):
+        if len(tensors) != len(self.devices):
+            raise ValueError("one PCM tensor per device")
+        for t in tensors:
+            if t.dtype != torch.int16 or not t.is_contiguous():
+                raise ValueError("PCM tensors must be contiguous int16")
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def encode(self, pcm: Sequence[torch.Tensor], clips, out: torch.Tensor, chunk_frames: int = 0) -> None:
+        """pcm[i]: shard i's PCM (host tensor, or device tensor on devices[i]; the shard's pcm_offsets count from its start);
+        out: ONE uint8 tensor for the whole batch (host, or on devices[0])."""
+        if out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError("out must be contiguous uint8")
+        arr = _clips_array(clips)
+        rc = _lib.lib().qoa_multi_encode(self._h, arr, len(clips), self._bases(pcm), C.c_void_p(out.data_ptr()), chunk_frames)
+        if rc:
+            raise EncodeError(rc)
+
+    def decode(self, enc: torch.Tensor, clips, pcm: Sequence[torch.Tensor], chunk_frames: int = 0) -> None:
+        if enc.dtype != torch.uint8 or not enc.is_contiguous():
+            raise ValueError("enc must be contiguous uint8")
+        arr = _clips_array(clips)
+        rc = _lib.lib().qoa_multi_decode(self._h, arr, len(clips), C.c_void_p(enc.data_ptr()), self._bases(pcm), chunk_frames)
         if rc:
             raise DecodeError(rc)
 

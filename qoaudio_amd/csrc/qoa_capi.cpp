@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "qoa_format.h"
@@ -225,6 +226,30 @@ extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_
     return QOA_OK;
 }
 
+// The LDS-table step form spends fewer issue slots per slice than the cheap-quotient register form but has one LDS round trip
+// per step on its serial chain: it only pays once a launch gives every SIMD about 8 wavefronts to cover that latency
+// (measured, stereo clips x 32 frames: 4096 clips 72 vs 78 G samples/s, 8192: 81.5 vs 85.1, 16384: 91.9 vs 89.5 --
+// tools/k1lab/forms.py).
+static bool plan_lds_form(uint32_t flags, const EncGroup *g) {
+    if (flags & QOA_PLAN_LDS_TABLES) return true;
+    return !(flags & QOA_PLAN_NO_LDS_TABLES) && (g->n + g->cpw - 1) / g->cpw >= 8192u;
+}
+
+extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
+                                           uint32_t *lds_table_form) {
+    if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
+    uint32_t waves = 0, cpw = 0, lds = 0, biggest = 0;
+    for (auto *g : plan->groups) {
+        const uint32_t w = (g->n + g->cpw - 1) / g->cpw;
+        waves += w;
+        if (w > biggest) { biggest = w; cpw = (uint32_t)g->cpw; lds = plan_lds_form(plan->flags, g) ? 1u : 0u; }
+    }
+    if (wavefronts) *wavefronts = waves;
+    if (chains_per_wavefront) *chains_per_wavefront = cpw;
+    if (lds_table_form) *lds_table_form = lds;
+    return QOA_OK;
+}
+
 // kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
 // bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table,
 // bit5 no cheap-quotient speculative steps
@@ -234,15 +259,10 @@ extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, 
                       ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) |
                       ((plan->flags & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u);
     for (auto *g : plan->groups) {
-        // The LDS-table step form spends fewer issue slots per slice (505 vs 539 for the cheap-quotient register form) but has
-        // one LDS round trip per step on its serial chain: it only pays once a launch gives every SIMD about 8 wavefronts to
-        // cover that latency (measured, stereo clips x 32 frames: 4096 clips 72 vs 78 G samples/s, 8192: 81.5 vs 85.1,
-        // 16384: 91.9 vs 89.5 -- tools/k1lab/forms.py).
-        unsigned lds = 0;
-        if (plan->flags & QOA_PLAN_LDS_TABLES) lds = 16u;
-        else if (!(plan->flags & QOA_PLAN_NO_LDS_TABLES) && (g->n + g->cpw - 1) / g->cpw >= 8192u) lds = 16u;
+        const unsigned lds = plan_lds_form(plan->flags, g) ? 16u : 0u;
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
-                              kflags | lds, (unsigned long long *)plan->stats.p, (hipStream_t)stream),
+                              kflags | lds, (plan->flags & QOA_PLAN_COUNTERS) ? (unsigned long long *)plan->stats.p : nullptr,
+                              (hipStream_t)stream),
                 QOA_ENCODE_IO_ERROR);
     }
     return QOA_OK;
@@ -251,6 +271,7 @@ extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, 
 extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices,
                                      uint64_t *speculation_misses) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
+    if (!(plan->flags & QOA_PLAN_COUNTERS)) return fail_msg("plan was created without QOA_PLAN_COUNTERS", QOA_ENCODE_IO_ERROR);
     uint64_t h[3] = {0, 0, 0};
     HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR); // runs may be in flight on any stream; this is a diagnostic
     HIP_TRY(hipMemcpy(h, plan->stats.p, sizeof h, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
@@ -262,6 +283,7 @@ extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_s
 
 extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n) {
     if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
+    if (!(plan->flags & QOA_PLAN_COUNTERS)) return fail_msg("plan was created without QOA_PLAN_COUNTERS", QOA_ENCODE_IO_ERROR);
     uint64_t h[kCounters];
     HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpy(h, plan->stats.p, sizeof h, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
@@ -271,6 +293,10 @@ extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, si
 
 // ------------------------------------------------------------------------------------------------
 // Host-memory batch encode: time-sliced pipeline
+//
+// (The copies in and out use hipMemcpyDefault: `h_pcm` / `h_out` may be any pointer of the unified address space -- host
+// memory, pinned or not, memory of this device, or memory of a PEER device.  qoa_multi_* below relies on that: every
+// device of a multi-GPU batch runs this pipeline on its shard and its stage-out IS the delivery to the root device.)
 //
 // A batch whose PCM lives in host memory cannot hide PCIe behind the kernel by splitting it into groups of
 // clips: the kernel's duration is set by the serial chain, not by the number of clips.  It CAN be split along
@@ -384,7 +410,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                     gb += d.channels;
                     if (now && !uniform)
                         HIP_TRY(hipMemcpyAsync((int16_t *)P.pcm[b].p + pcm_reg[i], h_pcm + clips[i].pcm_offset + first * d.channels,
-                                               (size_t)now * d.channels * 2, hipMemcpyHostToDevice, P.s_in),
+                                               (size_t)now * d.channels * 2, hipMemcpyDefault, P.s_in),
                                 QOA_ENCODE_IO_ERROR);
                 }
             }
@@ -395,7 +421,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 const uint32_t now = (uint32_t)std::min<uint64_t>(d.samples - first, (uint64_t)F * kFrameLen);
                 HIP_TRY(hipMemcpy2DAsync(P.pcm[b].p, (pcm_reg[1] - pcm_reg[0]) * 2, h_pcm + clips[0].pcm_offset + first * d.channels,
                                          (clips[1].pcm_offset - clips[0].pcm_offset) * 2, (size_t)now * d.channels * 2, n_clips,
-                                         hipMemcpyHostToDevice, P.s_in),
+                                         hipMemcpyDefault, P.s_in),
                         QOA_ENCODE_IO_ERROR);
             }
             HIP_TRY(hipMemcpyAsync(P.chains[b].p, table[b].data(), table[b].size() * sizeof(EncChain), hipMemcpyHostToDevice, P.s_in),
@@ -438,7 +464,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 if (bytes)
                     HIP_TRY(hipMemcpy2DAsync(h_out + clips[0].out_offset + dst, clips[1].out_offset - clips[0].out_offset,
                                              (uint8_t *)P.enc[bo].p + src, enc_reg[1] - enc_reg[0], bytes, n_clips,
-                                             hipMemcpyDeviceToHost, P.s_out),
+                                             hipMemcpyDefault, P.s_out),
                             QOA_ENCODE_IO_ERROR);
             } else {
                 for (size_t i = 0; i < n_clips; i++) {
@@ -446,7 +472,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                     piece(clips[i].desc, &dst, &src, &bytes);
                     if (bytes)
                         HIP_TRY(hipMemcpyAsync(h_out + clips[i].out_offset + dst, (uint8_t *)P.enc[bo].p + enc_reg[i] + src, bytes,
-                                               hipMemcpyDeviceToHost, P.s_out),
+                                               hipMemcpyDefault, P.s_out),
                                 QOA_ENCODE_IO_ERROR);
                 }
             }
@@ -1059,7 +1085,7 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 if (!now) continue;
                 if (!uniform)
                     HIP_TRY(hipMemcpyAsync((uint8_t *)P.enc[b].p + enc_reg[i], h_enc + clips[i].out_offset + eo, eb,
-                                           hipMemcpyHostToDevice, P.s_in), QOA_DECODE_IO_ERROR);
+                                           hipMemcpyDefault, P.s_in), QOA_DECODE_IO_ERROR);
                 uint64_t pos = enc_reg[i], outp = pcm_reg[i], left = now;
                 while (left > 0) {
                     const uint32_t fl = (uint32_t)std::min<uint64_t>(left, kFrameLen);
@@ -1078,7 +1104,7 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 uint64_t eo, eb, first, now;
                 slice_of(clips[0].desc, j, &eo, &eb, &first, &now);
                 HIP_TRY(hipMemcpy2DAsync(P.enc[b].p, enc_reg[1] - enc_reg[0], h_enc + clips[0].out_offset + eo,
-                                         clips[1].out_offset - clips[0].out_offset, eb, n_clips, hipMemcpyHostToDevice, P.s_in),
+                                         clips[1].out_offset - clips[0].out_offset, eb, n_clips, hipMemcpyDefault, P.s_in),
                         QOA_DECODE_IO_ERROR);
             }
             HIP_TRY(T.upload(recs, P.s_in, false), QOA_DECODE_IO_ERROR);
@@ -1104,7 +1130,7 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 const qoa_desc &d = clips[0].desc;
                 HIP_TRY(hipMemcpy2DAsync(h_pcm + clips[0].pcm_offset + first * d.channels, (clips[1].pcm_offset - clips[0].pcm_offset) * 2,
                                          P.pcm[bo].p, (pcm_reg[1] - pcm_reg[0]) * 2, now * d.channels * 2, n_clips,
-                                         hipMemcpyDeviceToHost, P.s_out), QOA_DECODE_IO_ERROR);
+                                         hipMemcpyDefault, P.s_out), QOA_DECODE_IO_ERROR);
             } else {
                 for (size_t i = 0; i < n_clips; i++) {
                     const qoa_desc &d = clips[i].desc;
@@ -1112,7 +1138,7 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                     slice_of(d, jj, &eo, &eb, &first, &now);
                     if (now)
                         HIP_TRY(hipMemcpyAsync(h_pcm + clips[i].pcm_offset + first * d.channels, (int16_t *)P.pcm[bo].p + pcm_reg[i],
-                                               now * d.channels * 2, hipMemcpyDeviceToHost, P.s_out), QOA_DECODE_IO_ERROR);
+                                               now * d.channels * 2, hipMemcpyDefault, P.s_out), QOA_DECODE_IO_ERROR);
                 }
             }
             HIP_TRY(hipEventRecord(P.out_done[bo], P.s_out), QOA_DECODE_IO_ERROR);
@@ -1146,6 +1172,160 @@ extern "C" int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-GPU batches behind the C ABI (BASELINE config 4): ONE process, one host thread + one time-sliced
+// pipeline per device.
+//
+// Clips are independent, so a batch shards with no data-path collective: device i takes the i-th block of the block
+// partition (qoaudio_amd/dist.py: shard_range -- the first n_clips % n_devices shards hold one clip more).  The one exchange
+// the configuration names is the gather of the encoded streams on the root device, devices[0].  In this one-process form it
+// is not a separate step: every device runs the host pipeline above on its shard with `out` pointing INTO THE ROOT's
+// buffer, so the stage-out copy of time slice j -- a peer copy over the device's own xGMI link, driven by its copy
+// engines -- overlaps the kernel of slice j + 1, and the gather is complete one slice after the last kernel.
+// Transport: HIP peer copies (hipMemcpy*Async with hipMemcpyDefault between unified addresses; peer access is enabled when
+// the devices offer it, otherwise the runtime stages through host memory).  RCCL's grouped ncclSend / ncclRecv is what the
+// one-process-per-GPU form uses (qoaudio_amd/dist.py under torch.distributed), where no rank can address a peer's memory;
+// a process that owns all devices needs no communicator and no copy kernels on the CUs K1 and K2 are using.
+// ------------------------------------------------------------------------------------------------
+struct qoa_multi {
+    std::vector<int> devices;
+    std::vector<qoa_host_pipeline *> pipes; // pipes[i] lives on devices[i]
+    ~qoa_multi() {
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        for (size_t i = 0; i < pipes.size(); i++) {
+            if (!pipes[i]) continue;
+            (void)hipSetDevice(devices[i]);
+            delete pipes[i];
+        }
+        if (have) (void)hipSetDevice(cur);
+    }
+};
+
+extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out) {
+    if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
+    *out = nullptr;
+    if (!devices || n_devices < 1) return fail_msg("qoa_multi_create: empty device list", QOA_ENCODE_IO_ERROR);
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count), QOA_ENCODE_IO_ERROR);
+    for (int i = 0; i < n_devices; i++) {
+        if (devices[i] < 0 || devices[i] >= count) {
+            g_detail = "qoa_multi_create: device " + std::to_string(devices[i]) + " does not exist (" + std::to_string(count) +
+                       " visible)";
+            return QOA_ENCODE_IO_ERROR;
+        }
+        for (int k = 0; k < i; k++)
+            if (devices[k] == devices[i]) return fail_msg("qoa_multi_create: a device is listed twice", QOA_ENCODE_IO_ERROR);
+    }
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur), QOA_ENCODE_IO_ERROR);
+    auto *m = new (std::nothrow) qoa_multi();
+    if (!m) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
+    m->devices.assign(devices, devices + n_devices);
+    m->pipes.assign((size_t)n_devices, nullptr);
+    int rc = QOA_OK;
+    for (int i = 0; i < n_devices && rc == QOA_OK; i++) {
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) {
+            m->pipes[(size_t)i] = new (std::nothrow) qoa_host_pipeline();
+            e = m->pipes[(size_t)i] ? m->pipes[(size_t)i]->init() : hipErrorOutOfMemory;
+        }
+        if (e == hipSuccess && i > 0) { // direct stores into the root's memory where the link allows it
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+                else (void)hipGetLastError(); // "already enabled" is sticky otherwise
+            }
+        }
+        if (e != hipSuccess) rc = fail_hip(e, "qoa_multi_create", QOA_ENCODE_IO_ERROR);
+    }
+    (void)hipSetDevice(cur);
+    if (rc != QOA_OK) { delete m; return rc; }
+    *out = m;
+    return QOA_OK;
+}
+
+extern "C" void qoa_multi_free(qoa_multi *m) { delete m; }
+
+extern "C" int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t *first, size_t *count) {
+    if (n_devices < 1 || index < 0 || index >= n_devices || !first || !count) return fail_msg("qoa_multi_shard: bad arguments", QOA_ENCODE_IO_ERROR);
+    const size_t base = n_clips / (size_t)n_devices, extra = n_clips % (size_t)n_devices, i = (size_t)index;
+    *first = i * base + std::min(i, extra);
+    *count = base + (i < extra ? 1 : 0);
+    return QOA_OK;
+}
+
+// runs fn(i) on one host thread per device that has work, each bound to its device; first failure wins
+template <class Fn>
+static int multi_run(qoa_multi *m, size_t n_clips, int io_error, Fn fn) {
+    const int n = (int)m->devices.size();
+    std::vector<int> rcs((size_t)n, QOA_OK);
+    std::vector<std::string> details((size_t)n);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n; i++) {
+        size_t first = 0, count = 0;
+        (void)qoa_multi_shard(n_clips, n, i, &first, &count);
+        if (!count) continue;
+        threads.emplace_back([&, i, first, count]() {
+            const hipError_t e = hipSetDevice(m->devices[(size_t)i]);
+            rcs[(size_t)i] = e == hipSuccess ? fn(i, first, count) : fail_hip(e, "hipSetDevice", io_error);
+            if (rcs[(size_t)i] != QOA_OK) details[(size_t)i] = "device " + std::to_string(m->devices[(size_t)i]) + ": " + g_detail;
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int i = 0; i < n; i++)
+        if (rcs[(size_t)i] != QOA_OK) { g_detail = details[(size_t)i]; return rcs[(size_t)i]; }
+    return QOA_OK;
+}
+
+extern "C" int qoa_multi_encode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const int16_t *const *pcm, uint8_t *out,
+                                uint32_t chunk_frames) {
+    if (!m || !clips || !pcm || !out) return fail_msg("qoa_multi_encode: null pointer", QOA_ENCODE_IO_ERROR);
+    for (size_t i = 0; i < n_clips; i++) { // the whole batch is validated before any device starts (src/lib.rs:336-344)
+        const int rc = validate_desc(&clips[i].desc);
+        if (rc) return rc;
+    }
+    return multi_run(m, n_clips, QOA_ENCODE_IO_ERROR, [&](int i, size_t first, size_t count) {
+        if (!pcm[i]) return fail_msg("qoa_multi_encode: null PCM base of a shard", QOA_ENCODE_IO_ERROR);
+        return host_pipe_encode(*m->pipes[(size_t)i], clips + first, count, pcm[i], out, chunk_frames);
+    });
+}
+
+extern "C" int qoa_multi_decode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const uint8_t *enc, int16_t *const *pcm,
+                                uint32_t chunk_frames) {
+    if (!m || !clips || !pcm || !enc) return fail_msg("qoa_multi_decode: null pointer", QOA_DECODE_IO_ERROR);
+    return multi_run(m, n_clips, QOA_DECODE_IO_ERROR, [&](int i, size_t first, size_t count) {
+        if (!pcm[i]) return fail_msg("qoa_multi_decode: null PCM base of a shard", QOA_DECODE_IO_ERROR);
+        return host_pipe_decode(*m->pipes[(size_t)i], clips + first, count, enc, pcm[i], chunk_frames);
+    });
+}
+
+// one-shot forms: the handle lives for one call
+extern "C" int qoa_encode_batch_multi(const int *devices, int n_devices, const qoa_clip *clips, size_t n_clips,
+                                      const int16_t *const *pcm, uint8_t *out, uint32_t chunk_frames) {
+    qoa_multi *m = nullptr;
+    int rc = qoa_multi_create(devices, n_devices, &m);
+    if (rc != QOA_OK) return rc;
+    rc = qoa_multi_encode(m, clips, n_clips, pcm, out, chunk_frames);
+    const std::string keep = g_detail;
+    qoa_multi_free(m);
+    g_detail = keep;
+    return rc;
+}
+
+extern "C" int qoa_decode_batch_multi(const int *devices, int n_devices, const qoa_clip *clips, size_t n_clips, const uint8_t *enc,
+                                      int16_t *const *pcm, uint32_t chunk_frames) {
+    qoa_multi *m = nullptr;
+    int rc = qoa_multi_create(devices, n_devices, &m);
+    if (rc != QOA_OK) return rc == QOA_ENCODE_IO_ERROR ? QOA_DECODE_IO_ERROR : rc;
+    rc = qoa_multi_decode(m, clips, n_clips, enc, pcm, chunk_frames);
+    const std::string keep = g_detail;
+    qoa_multi_free(m);
+    g_detail = keep;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // QoaDecoder handle
 // ------------------------------------------------------------------------------------------------
 struct qoa_decoder {
@@ -1166,8 +1346,45 @@ struct qoa_decoder {
     hipStream_t stream = nullptr;
     DevBuf d_in, d_out;
     DecTables tables;
+    // lazy reader (qoa_decoder_new_reader): bytes are pulled one frame at a time as the iterator runs dry
+    qoa_read_fn read = nullptr;
+    void *read_ctx = nullptr;
+    bool read_eof = false, read_failed = false;
     ~qoa_decoder() { if (stream) (void)hipStreamDestroy(stream); }
 };
+
+// read_exact over the callback: appends up to `want` bytes to dec->data, retrying short reads; returns how many arrived.
+// 0 bytes from the callback = end of stream, a negative value = an I/O error of the caller's reader.
+static size_t reader_pull(qoa_decoder *dec, size_t want) {
+    const size_t base = dec->data.size();
+    dec->data.resize(base + want);
+    size_t got = 0;
+    while (got < want && !dec->read_eof && !dec->read_failed) {
+        const int64_t n = dec->read(dec->read_ctx, dec->data.data() + base + got, want - got);
+        if (n < 0) dec->read_failed = true;
+        else if (n == 0) dec->read_eof = true;
+        else got += (size_t)std::min<uint64_t>((uint64_t)n, want - got);
+    }
+    dec->data.resize(base + got);
+    return got;
+}
+
+// Pull the next frame from the reader: its 8-byte header first, then -- when the header passes the checks the reference
+// makes before it reads on (src/lib.rs:227-244) -- the LMS block and the slice rows the header announces (:271-281, :679-682).
+// The reference issues these reads slice by slice as the iterator advances; here they happen together at the frame's
+// start, so the reader is never more than one frame ahead of the items handed out.
+static void reader_pull_frame(qoa_decoder *dec) {
+    const size_t at = dec->data.size();
+    if (reader_pull(dec, 8) < 8) return;
+    const uint64_t fh = be64(dec->data.data() + at);
+    const size_t nch = (size_t)(fh >> 56), rate = (size_t)((fh >> 32) & 0xffffff), nspc = (size_t)((fh >> 16) & 0xffff),
+                 fsize = (size_t)(fh & 0xffff);
+    const size_t non_sample = kHeaderSize + kLmsLen * 4 * nch;
+    if (nch == 0 || rate == 0 || fsize <= non_sample || ((fsize - non_sample) / 8) % nch != 0 ||
+        (fsize - non_sample) / 8 / nch > (size_t)kSlicesPerFrame)
+        return; // Walker::walk reports InvalidFrameHeader from the header alone, as the reference does
+    (void)reader_pull(dec, 16 * nch + (nspc + kSliceLen - 1) / kSliceLen * 8 * nch);
+}
 
 // Decode frames [first_frame, end) on the GPU and append their PCM to dec->pcm.
 static int decoder_decode_new_frames(qoa_decoder *dec, size_t first_frame) {
@@ -1204,7 +1421,21 @@ static int decoder_decode_new_frames(qoa_decoder *dec, size_t first_frame) {
 static int decoder_advance(qoa_decoder *dec) {
     size_t first_new = dec->frames.size();
     dec->terminal = dec->w.walk(dec->data.data(), dec->data.size(), &dec->pos, dec->frames);
+    // a reader that FAILED (not: ended) at a frame boundary is an IoError, not the clean end a short header read means
+    // (src/lib.rs:206-216 treats only UnexpectedEof as the end)
+    if (dec->read_failed && dec->terminal == kTermEnd) dec->terminal = QOA_DECODE_IO_ERROR;
     return decoder_decode_new_frames(dec, first_new);
+}
+
+// lazy mode: the iterator has used up the frames it has -- fetch one more frame, if the reader has one
+static bool decoder_refill(qoa_decoder *dec, int *rc) {
+    *rc = QOA_OK;
+    if (!dec->read || dec->read_eof || dec->read_failed || dec->terminal != kTermEnd) return false;
+    const size_t before = dec->data.size();
+    reader_pull_frame(dec);
+    if (dec->data.size() == before && !dec->read_failed) return false; // clean end of stream
+    *rc = decoder_advance(dec);
+    return true;
 }
 
 extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **out) { // src/lib.rs:127-169
@@ -1230,6 +1461,42 @@ extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **o
             if (t == kTermEnd) return QOA_DECODE_NO_SAMPLES;
             if (t == QOA_DECODE_IO_ERROR) g_detail = "failed to fill whole buffer";
             return t;
+        }
+        dec->current.num_channels = dec->frames[0].channels;
+        dec->current.sample_rate = dec->frames[0].rate;
+        dec->current.num_samples_per_channel = dec->frames[0].nspc;
+    }
+    *out = dec;
+    return QOA_OK;
+}
+
+// QoaDecoder::new over a reader that is pulled lazily (src/lib.rs:127-169): the magic and the sample count now, the first
+// frame inside new() when the count is non-zero (the reference parses its header + LMS there, :161-166), every later frame
+// when Iterator::next runs out of samples.
+extern "C" int qoa_decoder_new_reader(qoa_read_fn read, void *ctx, qoa_decoder **out) {
+    if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
+    *out = nullptr;
+    if (!read) return fail_msg("null reader callback", QOA_DECODE_IO_ERROR);
+    auto *dec = new (std::nothrow) qoa_decoder();
+    if (!dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+    dec->read = read;
+    dec->read_ctx = ctx;
+    auto fail = [&](int code, const char *msg) { if (msg) g_detail = msg; delete dec; return code; };
+    if (reader_pull(dec, 4) < 4) return fail(QOA_DECODE_IO_ERROR, dec->read_failed ? "reader callback failed" : "failed to fill whole buffer");
+    if (be32(dec->data.data()) != kMagic) return fail(QOA_DECODE_NOT_QOA_FILE, nullptr);
+    if (reader_pull(dec, 4) < 4) return fail(QOA_DECODE_IO_ERROR, dec->read_failed ? "reader callback failed" : "failed to fill whole buffer");
+    dec->pos = 8;
+    const uint32_t samples = be32(dec->data.data() + 4);
+    dec->w.mode = samples == 0 ? kStreaming : kFixed;
+    dec->w.fixed_samples = samples;
+    if (dec->w.mode == kFixed) {
+        reader_pull_frame(dec);
+        const int rc = decoder_advance(dec);
+        if (rc) return fail(rc, nullptr);
+        if (dec->frames.empty()) {
+            const int t = dec->terminal;
+            if (t == kTermEnd) return fail(QOA_DECODE_NO_SAMPLES, nullptr);
+            return fail(t, t == QOA_DECODE_IO_ERROR ? (dec->read_failed ? "reader callback failed" : "failed to fill whole buffer") : nullptr);
         }
         dec->current.num_channels = dec->frames[0].channels;
         dec->current.sample_rate = dec->frames[0].rate;
@@ -1306,10 +1573,17 @@ extern "C" int qoa_decoder_next(qoa_decoder *dec, qoa_item *item) {
             item->header = dec->current;
             return QOA_OK;
         }
+        {   // lazy reader: the next frame is fetched only now (src/lib.rs:684)
+            int rc;
+            if (decoder_refill(dec, &rc)) {
+                if (rc) { item->kind = QOA_ITEM_ERROR; item->error = rc; dec->finished_err = true; return QOA_OK; }
+                continue;
+            }
+        }
         if (dec->terminal == kTermEnd) { item->kind = QOA_ITEM_END; return QOA_OK; } // :686
         item->kind = QOA_ITEM_ERROR;
         item->error = dec->terminal;
-        if (dec->terminal == QOA_DECODE_IO_ERROR) g_detail = "failed to fill whole buffer";
+        if (dec->terminal == QOA_DECODE_IO_ERROR) g_detail = dec->read_failed ? "reader callback failed" : "failed to fill whole buffer";
         dec->finished_err = true;
         return QOA_OK;
     }

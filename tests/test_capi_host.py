@@ -352,3 +352,34 @@ def _check_wait_states(g, body):
             if r in last_write and last_write[r][1].startswith("v_dot2") and not op.startswith("v_dot2"):
                 assert pos - last_write[r][0] >= 5, line
             last_write[r] = (pos, op)
+
+
+def test_multi_gpu_shards_equal_dist_shard_range():
+    """qoa_multi_shard (the C ABI's block partition) == qoaudio_amd.dist.shard_range (the torch.distributed form)."""
+    from qoaudio_amd import batch, dist
+    for n in (0, 1, 7, 8, 1024, 8191, 8192):
+        for world in (1, 2, 3, 8):
+            covered = 0
+            for r in range(world):
+                first, count = batch.multi_shard(n, world, r)
+                assert (first, first + count) == dist.shard_range(n, r, world)
+                covered += count
+            assert covered == n
+
+
+def test_multi_gpu_and_lazy_reader_fail_loudly_without_a_device():
+    """No CPU fallback: on a box without a GPU qoa_multi_create returns IoError with a detail string; the lazy reader's
+    checks that precede any decoding (magic, header length) give the reference's errors."""
+    import torch
+    import qoaudio_amd as q
+    from qoaudio_amd import batch, _lib
+    import io
+    if not torch.cuda.is_available():
+        with pytest.raises(q.EncodeError) as e:
+            batch.MultiGpu([0])
+        assert e.value.kind == "IoError" and _lib.lib().qoa_last_error_detail()
+    for data, kind in ((b"riff\0\0\0\1" + bytes(64), "NotQoaFile"), (b"qo", "IoError"), (b"qoaf\0\0", "IoError"),
+                       (b"qoaf\0\0\0\1", "NoSamples"), (b"qoaf\0\0\0\1" + bytes(8), "InvalidFrameHeader")):
+        with pytest.raises(q.DecodeError) as e:
+            q.QoaDecoder(io.BytesIO(data))
+        assert e.value.kind == kind

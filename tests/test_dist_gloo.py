@@ -85,11 +85,11 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` without a launcher starts its own rank processes -- but only after checking, without
     initialising any device, that N GPUs exist.  On this CPU-only box that check must fail fast and loudly."""
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     if torch.cuda.device_count() >= 2:
         pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--clips", "4", "--frames", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2
     assert "only" in r.stderr and "GPU" in r.stderr
     assert r.stdout.strip() == ""

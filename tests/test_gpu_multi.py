@@ -7,10 +7,11 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import ROOT, rng_pcm
 
 pytestmark = pytest.mark.gpu
 
@@ -53,3 +54,124 @@ def test_two_rank_control_flow_on_one_gpu(gpu, oracle):
     assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)
     assert line["config"]["samples_per_step"] == 2 * 64 * 8 * 5120 * 2
     assert line["decode"]["header_mismatches"] == 0
+
+
+def test_two_rank_control_flow_at_config4_per_rank_shape(gpu, oracle):
+    """The same two-rank run at config 4's REAL per-rank shape -- 1024 stereo clips x 256 frames per rank: 5.37 GB of PCM,
+    1.08 GB encoded shards, two output buffers per rank and two 2.17 GB gather destinations on rank 0, rotated by the
+    double-buffered gather loop.  Not a measurement (both ranks share device 0, the gather is staged through host memory
+    over gloo); it proves the allocation sizes, the buffer rotation and the launcher at full size before an 8-GPU box
+    ever sees them."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QOA_BENCH_SHARE_GPU="1", QOA_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--clips", "1024", "--frames", "256", "--no-cpu", "--no-extras", "--no-decode"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    per_enc = gpu.encoded_size(2, 256 * 5120)
+    assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo"
+    assert line["config"]["encoded_bytes_per_gpu"] == 1024 * per_enc == 1084235776
+    assert line["gathered_bytes"] == 2 * 1024 * per_enc
+    assert line["bit_exact_vs_oracle"] is True and line["gathered_shards_bit_exact_vs_oracle"] is True
+    assert line["config"]["samples_per_step"] == 2 * 1024 * 256 * 5120 * 2
+
+
+def test_bench_abi_multi_one_device(gpu):
+    """`bench.py --abi-multi --gpus 1`: the C ABI's one-process multi-GPU form with the only device count this box has;
+    same JSON keys as the torch.distributed form."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--abi-multi", "--gpus", "1", "--steps", "2",
+                          "--warmup", "1", "--clips", "64", "--frames", "16"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["multi_gpu_path"] == "c-abi" and line["unit"] == "samples/s"
+    assert line["bit_exact_vs_oracle"] is True and line["gathered_shards_bit_exact_vs_oracle"] is True
+    assert line["gathered_bytes"] == 64 * gpu.encoded_size(2, 16 * 5120)
+    for key in ("metric", "value", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline"):
+        assert key in line
+
+
+# ---- multi-GPU behind the C ABI (qoa_multi_*, include/qoaudio_amd.h): one process, one pipeline per device ----
+
+def _ragged_batch(gpu):
+    descs = [gpu.QoaDesc(2, 44100, 3 * 5120 + 77), gpu.QoaDesc(1, 8000, 5120), gpu.QoaDesc(2, 44100, 19),
+             gpu.QoaDesc(8, 48000, 2 * 5120 + 1), gpu.QoaDesc(3, 22050, 4000), gpu.QoaDesc(2, 44100, 2 * 5120)]
+    clips, po, oo = [], 0, 0
+    for d in descs:
+        clips.append((po, oo, d))
+        po += d.samples * d.channels
+        oo += (gpu.encoded_size(d.channels, d.samples) + 7) // 8 * 8
+    return clips, po, oo
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_abi_multi_one_device_vs_oracle(gpu, oracle, where):
+    """qoa_multi_encode / qoa_multi_decode with n_devices = 1 (what this box can run): a ragged 1..8-channel batch and a
+    uniform stereo batch, PCM and output on the device or in host memory, every clip against the oracle."""
+    from qoaudio_amd import batch
+    m = batch.MultiGpu([0])
+    dev = "cuda:0" if where == "device" else "cpu"
+    for uniform in (False, True):
+        if uniform:
+            d = gpu.QoaDesc(2, 44100, 9 * 5120 + 333)
+            clips, per_pcm, per_enc = batch.uniform_clips(24, d)
+            n_pcm, n_enc = 24 * per_pcm, 24 * per_enc
+        else:
+            clips, n_pcm, n_enc = _ragged_batch(gpu)
+        host = rng_pcm(77 + uniform, n_pcm, "mix")
+        pcm = torch.from_numpy(host).to(dev)
+        out = torch.zeros(n_enc, dtype=torch.uint8, device=dev)
+        m.encode([pcm], clips, out, chunk_frames=2)
+        he = out.cpu().numpy()
+        for po, oo, d in clips:
+            want = oracle.encode_all(host[po:po + d.samples * d.channels], d.channels, d.sample_rate, d.samples)
+            assert he[oo:oo + len(want)].tobytes() == want
+        back = torch.zeros(n_pcm, dtype=torch.int16, device=dev)
+        m.decode(out, clips, [back], chunk_frames=2)
+        hb = back.cpu().numpy()
+        for po, oo, d in clips:
+            n = d.samples * d.channels
+            _, _, want = oracle.decode_all(he[oo:oo + gpu.encoded_size(d.channels, d.samples)].tobytes())
+            assert np.array_equal(hb[po:po + n], want)
+
+
+def test_abi_multi_errors_never_abort(gpu):
+    from qoaudio_amd import batch, _lib
+    n = torch.cuda.device_count()
+    for devs in ([n], [-1], [0, 0], []):
+        with pytest.raises(gpu.EncodeError) as e:
+            batch.MultiGpu(devs)
+        assert e.value.kind == "IoError"
+        assert _lib.lib().qoa_last_error_detail()
+    m = batch.MultiGpu([0])
+    bad = [(0, 0, gpu.QoaDesc(9, 44100, 100))]
+    with pytest.raises(gpu.EncodeError) as e:
+        m.encode([torch.zeros(900, dtype=torch.int16)], bad, torch.zeros(4096, dtype=torch.uint8))
+    assert e.value.kind == "InvalidChannels"
+
+
+def test_abi_multi_two_devices(gpu, oracle):
+    """The real thing: two shards on two devices, the encoded streams gathered in device 0's buffer by peer copies."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    from qoaudio_amd import batch
+    d = gpu.QoaDesc(2, 44100, 6 * 5120 + 5)
+    clips, per_pcm, per_enc = batch.uniform_clips(37, d)
+    host = rng_pcm(5, 37 * per_pcm, "mix")
+    m = batch.MultiGpu([0, 1])
+    shards, bases = [], []
+    for i in range(2):
+        first, count = batch.multi_shard(37, 2, i)
+        shards.append(torch.from_numpy(host[first * per_pcm:(first + count) * per_pcm]).to(f"cuda:{i}"))
+        bases.append(first)
+    # a shard's pcm_offsets count from the shard's own base
+    n0 = batch.multi_shard(37, 2, 0)[1]
+    rel = [(po - (0 if k < n0 else bases[1]) * per_pcm, oo, dd) for k, (po, oo, dd) in enumerate(clips)]
+    out = torch.zeros(37 * per_enc, dtype=torch.uint8, device="cuda:0")
+    m.encode(shards, rel, out, chunk_frames=2)
+    he = out.cpu().numpy()
+    for k, (po, oo, dd) in enumerate(clips):
+        assert he[oo:oo + per_enc].tobytes() == oracle.encode_all(host[po:po + per_pcm], 2, 44100, d.samples)

@@ -212,6 +212,84 @@ def test_decoder_item_order_matches_reference_iterator(gpu, oracle):
                 break
 
 
+class _ChunkReader:
+    """io::Read stand-in: hands out `sizes[k % len]` bytes per call (short reads), optionally fails at byte `fail_at`."""
+
+    def __init__(self, data, sizes, fail_at=None):
+        self.data, self.sizes, self.fail_at, self.pos, self.calls = bytes(data), sizes, fail_at, 0, 0
+
+    def read(self, n):
+        if self.fail_at is not None and self.pos >= self.fail_at:
+            raise OSError("reader failed")
+        k = min(n, self.sizes[self.calls % len(self.sizes)], len(self.data) - self.pos)
+        if self.fail_at is not None:
+            k = min(k, self.fail_at - self.pos) or k
+        self.calls += 1
+        out = self.data[self.pos:self.pos + k]
+        self.pos += len(out)
+        return out
+
+
+def _items(dec, gpu):
+    out = []
+    while True:
+        try:
+            it = dec.next()
+        except gpu.DecodeError as e:
+            out.append(("Err", e.kind))
+            return out
+        if it is None:
+            return out
+        out.append(("FrameHeader", (it.num_channels, it.sample_rate, it.num_samples_per_channel))
+                   if isinstance(it, gpu.FrameHeader) else ("Sample", it.value))
+
+
+def test_lazy_reader_item_order_and_position(gpu, oracle):
+    """qoa_decoder_new_reader (QoaDecoder::new over io::Read, src/lib.rs:127-178, :668-692): the item sequence over a
+    reader that returns 1..7 bytes per call equals the oracle's iterator over the same bytes -- well-formed, truncated
+    inside a row, cut at a frame boundary, streaming mode with changing channel counts; the reader is pulled frame by frame
+    (never further than the frame whose samples are being handed out), and into_inner() returns it there."""
+    x2 = rng_pcm(21, 5200 * 2)
+    enc2 = oracle.encode_all(x2, 2, 32000, 5200)      # two frames: 5120 + 80 sample-times
+    x3 = rng_pcm(22, 130 * 3)
+    enc3 = oracle.encode_all(x3, 3, 8000, 130)
+    streaming = b"qoaf\0\0\0\0" + enc2[8:] + enc3[8:] + enc2[8:]
+    for data in (enc2, enc3, enc2[:-5], enc2[: 8 + 4136], enc2[: 8 + 4136 + 3], streaming, streaming[:-9]):
+        want = [w for w in oracle.OracleDecoder(data)]
+        rd = _ChunkReader(data, [1, 7, 3, 5, 2, 6, 4])
+        dec = gpu.QoaDecoder(rd)
+        got = _items(dec, gpu)
+        assert got == want, (len(data), got[:3], want[:3])
+    # laziness: after new() only the file header and the first frame have been pulled; the second frame arrives when the
+    # iterator has handed out the first one's last sample
+    rd = _ChunkReader(enc2, [4096])
+    dec = gpu.QoaDecoder(rd)
+    first_frame_end = 8 + 4136
+    assert rd.pos == first_frame_end
+    assert isinstance(dec.next(), gpu.FrameHeader)
+    for _ in range(5120 * 2):
+        assert isinstance(dec.next(), gpu.Sample)
+    assert rd.pos == first_frame_end
+    assert dec.next() == gpu.FrameHeader(2, 32000, 80)
+    assert rd.pos == len(enc2)
+    inner = dec.into_inner()
+    assert inner is rd and inner.pos == len(enc2)
+    # a reader that FAILS (not: ends) -- in the middle of the second frame, and exactly at a frame boundary: the rows that
+    # arrived are yielded, then IoError (src/lib.rs:206-216 treats only UnexpectedEof as a clean end)
+    for fail_at, n_samples in ((8 + 4136 + 8 + 32 + 16 * 2 + 5, (5120 + 40) * 2), (8 + 4136, 5120 * 2)):
+        got = _items(gpu.QoaDecoder(_ChunkReader(enc2, [7, 1, 64], fail_at=fail_at)), gpu)
+        assert got[-1] == ("Err", "IoError")
+        assert sum(1 for k, _ in got if k == "Sample") == n_samples
+    # errors of new(): bad magic, nothing but the file header, reader failing inside the first 8 bytes
+    for data, kind in ((b"riff" + enc2[4:], "NotQoaFile"), (enc2[:8], "NoSamples"), (enc2[:3], "IoError")):
+        with pytest.raises(gpu.DecodeError) as e:
+            gpu.QoaDecoder(_ChunkReader(data, [2]))
+        assert e.value.kind == kind
+    with pytest.raises(gpu.DecodeError) as e:
+        gpu.QoaDecoder(_ChunkReader(enc2, [3], fail_at=5))
+    assert e.value.kind == "IoError"
+
+
 def test_streaming_decoder_decode_frame(gpu, oracle, fixture_bytes):
     """src/lib.rs:1034-1066, plus sample values and a multi-frame append."""
     dec = gpu.QoaDecoder.new_streaming()
@@ -456,7 +534,7 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     pcm = torch.from_numpy(fixture_pcm).cuda()
     outs = []
     for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT):
-        plan = batch.EncodePlan(clips, flags)
+        plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
         declined, unpacked, misses = plan.stats()
@@ -496,7 +574,7 @@ def test_cheap_quotient_on_loud_material(gpu, oracle, fixture_pcm, gain):
     pcm = torch.from_numpy(x).cuda()
     outs, declines, marks = [], [], []
     for flags in (batch.PLAN_DEFAULT, batch.PLAN_EXACT_QUOTIENT, batch.PLAN_CPW_1):
-        plan = batch.EncodePlan(clips, flags)
+        plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
         c = plan.counters()

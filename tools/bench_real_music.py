@@ -18,7 +18,7 @@ desc = q.QoaDesc(2, 44100, samples)
 clips, _, per_enc = batch.uniform_clips(n_clips, desc)
 for name, fl in (("default", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT), ("no speculation", batch.PLAN_NO_SPECULATION),
                  ("32-bit step", batch.PLAN_FORCE_32BIT_STEP)):
-    plan = batch.EncodePlan(clips, fl)
+    plan = batch.EncodePlan(clips, fl | batch.PLAN_COUNTERS)
     out = torch.empty((n_clips, per_enc), dtype=torch.uint8, device="cuda")
     plan.run(pcm, out); torch.cuda.synchronize()
     ms = []

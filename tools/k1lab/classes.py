@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""K1 on the signal classes of SURVEY 8(d) at config 3's chain count (CLIPS stereo clips x FRAMES frames): kernel time and the
+plan counters per class and plan flag set.  Run on the GPU box:  python tools/k1lab/classes.py [frames [clips]]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from qoaudio_amd import batch, synth  # noqa: E402
+import qoaudio_amd as gpu  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n_clips, ch = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 2
+samples = frames * 5120
+per = samples * ch
+enc = gpu.encoded_size(ch, samples)
+clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
+for kind in ("music", "white", "silence", "loud"):
+    if kind == "loud":  # the music class amplified 3x into clipping
+        pcm = (synth.make_clips(n_clips, samples, ch, 44100, device="cuda").to(torch.int32) * 3).clamp_(-32768, 32767).to(torch.int16)
+    else:
+        pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda", kind=kind)
+    ref = None
+    for name, fl in (("default", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT), ("no speculation", batch.PLAN_NO_SPECULATION)):
+        plan = batch.EncodePlan(clips, fl | batch.PLAN_COUNTERS)
+        out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
+        plan.run(pcm.view(-1), out)
+        torch.cuda.synchronize()
+        s0 = plan.counters()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            plan.run(pcm.view(-1), out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        if ref is None:
+            ref = out.clone()
+        same = bool(torch.equal(ref, out))
+        slices = n_clips * ch * frames * 256
+        print(f"{kind:8s} {name:16s} {ms:8.3f} ms  {ms * 1e6 / (frames * 256):7.1f} ns/slice  declined/unpacked/spec-miss/cheap-declined/marked "
+              f"{s0} of {slices} slices  bytes equal: {same}", flush=True)

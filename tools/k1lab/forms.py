@@ -21,7 +21,7 @@ ref = None
 for name, fl in (("default", 0), ("cheap quotient, no LDS tables", batch.PLAN_NO_LDS_TABLES),
                  ("exact quotient, no LDS tables", batch.PLAN_EXACT_QUOTIENT | batch.PLAN_NO_LDS_TABLES),
                  ("no speculation", batch.PLAN_NO_SPECULATION), ("lds tables", batch.PLAN_LDS_TABLES)):
-    plan = batch.EncodePlan(clips, fl)
+    plan = batch.EncodePlan(clips, fl | batch.PLAN_COUNTERS)
     out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
     plan.run(pcm.view(-1), out)
     torch.cuda.synchronize()

@@ -39,6 +39,13 @@ def main():
         rd, wr = int(c["FETCH_SIZE"]) * 1024 * 2, int(c["WRITE_SIZE"]) * 1024
         res[name] = {"fetch_size_kb": int(c["FETCH_SIZE"]), "write_size_kb": int(c["WRITE_SIZE"]), "read_bytes_corrected": rd,
                      "write_bytes": wr, "traffic_bytes_per_launch": rd + wr, "source_sha256": bench.kernel_source_sha256(name)}
+    # K1's VALU wave-instructions per slice and wavefront for the step form config 3 runs (cheap-quotient register form):
+    # bench.py's valu_issue roofline reads it from here, tied to the same source hash as the traffic
+    enc = d["encode"]
+    if "SQ_INSTS_VALU" in enc and "SQ_WAVES" in enc:
+        res["encode"]["valu_per_slice"] = {"cheap_quotient": enc["SQ_INSTS_VALU"] / (enc["SQ_WAVES"] * 256 * 256)}
+        if "SQ_WAIT_ANY" in enc and "SQ_WAVE_CYCLES" in enc:
+            res["encode"]["sq_wait_any_frac"] = enc["SQ_WAIT_ANY"] / enc["SQ_WAVE_CYCLES"]
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
