@@ -408,7 +408,7 @@ def main():
         # the same batch runs once more, untimed, through a plan that counts.
         cplan = batch.EncodePlan(clips, batch.PLAN_COUNTERS)
         cplan.run(pcm, out, stream)
-        declined, unpacked, misses, cheap_declined, marked = cplan.counters()
+        declined, unpacked, misses, cheap_declined, marked = cplan.counters()[:5]
         result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked, "speculation_misses": misses,
                                  "cheap_quotient_declines": cheap_declined, "cheap_quotient_marked_wave_slices": marked,
                                  "slices_total": n_clips * ch * ((samples + 19) // 20), "launches": 1}

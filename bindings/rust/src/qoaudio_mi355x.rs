@@ -9,13 +9,14 @@
 //! against `include/qoaudio_amd.h` symbol by symbol (argument count, pointer depth, constness, integer width) -- the
 //! only verification possible without `rustc`.
 //!
-//! Differences a caller can observe: readers are drained eagerly in
-//! `QoaDecoder::new`; there is no CPU fallback (no usable GPU => `IoError`).
+//! Differences a caller can observe: `QoaDecoder::new(reader)` pulls the reader lazily but a
+//! whole FRAME at a time (the reference reads it slice row by slice row), so `into_inner()` in the middle of a frame
+//! returns the reader at that frame's end; there is no CPU fallback (no usable GPU => `IoError`).
 use std::ffi::CStr;
 use std::fmt::Display;
 use std::fs::File;
 use std::io::Cursor;
-use std::os::raw::{c_char, c_double, c_int};
+use std::os::raw::{c_char, c_double, c_int, c_void};
 use std::path::Path;
 use std::time::Duration;
 use std::{fmt, io};
@@ -32,6 +33,7 @@ pub const QOA_MAX_CHANNELS: usize = 8; // :19
 mod ffi {
     use super::*;
     #[repr(C)]
+    #[derive(Clone, Copy)]
     pub struct qoa_desc {
         pub channels: u8,
         pub sample_rate: u32,
@@ -60,8 +62,18 @@ mod ffi {
         pub header: qoa_frame_header,
         pub error: c_int,
     }
+    #[repr(C)]
+    #[derive(Clone, Copy)]
+    pub struct qoa_clip {
+        pub pcm_offset: u64,
+        pub out_offset: u64,
+        pub desc: qoa_desc,
+    }
     pub enum qoa_encoder {}
     pub enum qoa_decoder {}
+    pub enum qoa_multi {}
+    /// `int64_t (*)(void *ctx, uint8_t *buf, size_t len)`: bytes stored, 0 at the end of the stream, negative on error
+    pub type qoa_read_fn = unsafe extern "C" fn(*mut c_void, *mut u8, usize) -> i64;
     extern "C" {
         pub fn qoa_last_error_detail() -> *const c_char;
         pub fn qoa_encoded_size(channels: u32, samples: u32) -> usize;
@@ -73,6 +85,7 @@ mod ffi {
         pub fn qoa_encoder_encode_frame(enc: *mut qoa_encoder, pcm: *const i16, n_i16: usize, out: *mut u8,
                                         cap: usize, written: *mut usize, frame_len: *mut usize) -> c_int;
         pub fn qoa_decoder_new(bytes: *const u8, len: usize, out: *mut *mut qoa_decoder) -> c_int;
+        pub fn qoa_decoder_new_reader(read: qoa_read_fn, ctx: *mut c_void, out: *mut *mut qoa_decoder) -> c_int;
         pub fn qoa_decoder_new_streaming(out: *mut *mut qoa_decoder) -> c_int;
         pub fn qoa_decoder_free(dec: *mut qoa_decoder);
         pub fn qoa_decoder_mode(dec: *const qoa_decoder, mode: *mut qoa_mode) -> c_int;
@@ -83,6 +96,18 @@ mod ffi {
                                         cap: usize, n_out: *mut usize) -> c_int;
         pub fn qoa_decode_all(bytes: *const u8, len: usize, channels: *mut u8, sample_rate: *mut u32,
                               out: *mut i16, cap: usize, n_out: *mut usize) -> c_int;
+        // multi-GPU batches in one process (no counterpart in the reference; include/qoaudio_amd.h)
+        pub fn qoa_multi_create(devices: *const c_int, n_devices: c_int, out: *mut *mut qoa_multi) -> c_int;
+        pub fn qoa_multi_free(m: *mut qoa_multi);
+        pub fn qoa_multi_shard(n_clips: usize, n_devices: c_int, index: c_int, first: *mut usize, count: *mut usize) -> c_int;
+        pub fn qoa_multi_encode(m: *mut qoa_multi, clips: *const qoa_clip, n_clips: usize, pcm: *const *const i16,
+                                out: *mut u8, chunk_frames: u32) -> c_int;
+        pub fn qoa_multi_decode(m: *mut qoa_multi, clips: *const qoa_clip, n_clips: usize, enc: *const u8,
+                                pcm: *const *mut i16, chunk_frames: u32) -> c_int;
+        pub fn qoa_encode_batch_multi(devices: *const c_int, n_devices: c_int, clips: *const qoa_clip, n_clips: usize,
+                                      pcm: *const *const i16, out: *mut u8, chunk_frames: u32) -> c_int;
+        pub fn qoa_decode_batch_multi(devices: *const c_int, n_devices: c_int, clips: *const qoa_clip, n_clips: usize,
+                                      enc: *const u8, pcm: *const *mut i16, chunk_frames: u32) -> c_int;
     }
 }
 
@@ -253,17 +278,41 @@ pub fn encode_all(sample_data: &[i16], desc: &QoaDesc) -> Result<Vec<u8>, Encode
     encoder.encode(sample_data)
 }
 
-/// Decoder of QOA files (:47-68).  The reader is drained in `new`; the GPU decodes whole frames and `next`
-/// replays the reference's item order.  `mode` and `current_frame` mirror the reference's fields of the same purpose
-/// (:60, :63) so that the accessors can hand out references.
+/// Decoder of QOA files (:47-68).  The reader is pulled through a C callback, one frame at a time, as `next` runs out of
+/// samples (`qoa_decoder_new_reader`); the GPU decodes whole frames and `next` replays the reference's item order.  `mode`
+/// and `current_frame` mirror the reference's fields of the same purpose (:60, :63) so that the accessors can hand out
+/// references.
 #[derive(Debug)]
 pub struct QoaDecoder<R> {
     h: *mut ffi::qoa_decoder,
-    reader: Option<R>,
+    cell: Option<Box<ReaderCell<R>>>, // boxed: the C side keeps its address as the callback's context
     mode: ProcessingMode,
     current_frame: FrameHeader,
 }
 unsafe impl<R: Send> Send for QoaDecoder<R> {}
+
+/// The reader and the last error it raised (handed to the caller instead of a generic IoError).
+#[derive(Debug)]
+struct ReaderCell<R> {
+    reader: R,
+    error: Option<io::Error>,
+}
+
+/// `qoa_read_fn` over any `io::Read`: bytes stored, 0 at the end, -1 after an error (kept in the cell).
+unsafe extern "C" fn read_trampoline<R: io::Read>(ctx: *mut c_void, buf: *mut u8, len: usize) -> i64 {
+    let cell = &mut *(ctx as *mut ReaderCell<R>);
+    let dst = std::slice::from_raw_parts_mut(buf, len);
+    loop {
+        match cell.reader.read(dst) {
+            Ok(n) => return n as i64,
+            Err(e) if e.kind() == io::ErrorKind::Interrupted => continue, // as read_exact does
+            Err(e) => {
+                cell.error = Some(e);
+                return -1;
+            }
+        }
+    }
+}
 
 fn query_mode(h: *mut ffi::qoa_decoder) -> ProcessingMode {
     let mut m = ffi::qoa_mode::default();
@@ -281,17 +330,35 @@ fn query_header(h: *mut ffi::qoa_decoder) -> FrameHeader {
     FrameHeader { num_channels: fh.num_channels, sample_rate: fh.sample_rate, num_samples_per_channel: fh.num_samples_per_channel }
 }
 
+impl<R> QoaDecoder<R> {
+    /// IoError: the reader's own error when it raised one, else the library's detail string
+    fn map_err(&mut self, code: c_int) -> DecodeError {
+        if code == 5 {
+            if let Some(e) = self.cell.as_mut().and_then(|c| c.error.take()) {
+                return DecodeError::IoError(e);
+            }
+        }
+        dec_err(code)
+    }
+}
+
 impl<R: io::Read> QoaDecoder<R> {
     pub fn new(mut reader: R) -> Result<Self, DecodeError> { // :127-169
-        let mut bytes = Vec::new();
-        reader.read_to_end(&mut bytes)?;
+        let _ = &mut reader;
+        let mut cell = Box::new(ReaderCell { reader, error: None });
         let mut h = std::ptr::null_mut();
-        match unsafe { ffi::qoa_decoder_new(bytes.as_ptr(), bytes.len(), &mut h) } {
-            0 => Ok(Self { h, reader: Some(reader), mode: query_mode(h), current_frame: query_header(h) }),
+        let ctx = &mut *cell as *mut ReaderCell<R> as *mut c_void;
+        match unsafe { ffi::qoa_decoder_new_reader(read_trampoline::<R>, ctx, &mut h) } {
+            0 => Ok(Self { h, cell: Some(cell), mode: query_mode(h), current_frame: query_header(h) }),
+            5 if cell.error.is_some() => Err(DecodeError::IoError(cell.error.take().unwrap())),
             c => Err(dec_err(c)),
         }
     }
-    pub fn into_inner(mut self) -> R { self.reader.take().unwrap() } // :172-174
+    pub fn into_inner(mut self) -> R { // :172-174 -- the decoder goes first: it holds the cell's address
+        unsafe { ffi::qoa_decoder_free(self.h) };
+        self.h = std::ptr::null_mut();
+        self.cell.take().unwrap().reader
+    }
     pub fn mode(&self) -> &ProcessingMode { &self.mode } // :180-182
     pub fn current_frame_header(&self) -> &FrameHeader { &self.current_frame } // :186-188
     pub fn total_duration(&self) -> Option<Duration> { // :190-201
@@ -311,8 +378,8 @@ impl QoaDecoder<Cursor<Vec<u8>>> {
     pub fn new_streaming() -> Result<Self, DecodeError> { // :632-638
         let mut h = std::ptr::null_mut();
         match unsafe { ffi::qoa_decoder_new_streaming(&mut h) } {
-            0 => Ok(Self { h, reader: Some(Cursor::new(Vec::new())), mode: ProcessingMode::Streaming,
-                           current_frame: FrameHeader::default() }),
+            0 => Ok(Self { h, cell: Some(Box::new(ReaderCell { reader: Cursor::new(Vec::new()), error: None })),
+                           mode: ProcessingMode::Streaming, current_frame: FrameHeader::default() }),
             c => Err(dec_err(c)),
         }
     }
@@ -349,12 +416,16 @@ impl<R: io::Read> Iterator for QoaDecoder<R> { // :661-693
                 Some(Ok(QoaItem::FrameHeader(self.current_frame)))
             }
             2 => None,
-            _ => Some(Err(dec_err(it.error))),
+            _ => Some(Err(self.map_err(it.error))),
         }
     }
 }
 impl<R> Drop for QoaDecoder<R> {
-    fn drop(&mut self) { unsafe { ffi::qoa_decoder_free(self.h) } }
+    fn drop(&mut self) {
+        if !self.h.is_null() {
+            unsafe { ffi::qoa_decoder_free(self.h) } // before `cell` is dropped: the handle holds its address
+        }
+    }
 }
 
 /// Decode all samples of a QOA file read from `reader`. (:706-747)
@@ -376,4 +447,67 @@ pub fn decode_all<R: io::Read>(mut reader: R) -> Result<DecodedQoa, DecodeError>
 pub fn open_and_decode_all<P: AsRef<Path>>(path: P) -> Result<DecodedQoa, DecodeError> {
     let file = File::open(path.as_ref())?;
     decode_all(io::BufReader::new(file))
+}
+
+/// One clip of a batch (`qoa_clip`): `pcm_offset` counts i16 elements from its shard's PCM base, `out_offset` bytes from the
+/// batch's output base.
+#[derive(Debug, Clone)]
+pub struct BatchClip {
+    pub pcm_offset: u64,
+    pub out_offset: u64,
+    pub desc: QoaDesc,
+}
+
+/// Several GPUs driven from one process (`qoa_multi_*`; no counterpart in the reference, which is single-threaded: per
+/// clip this is `encode_all`, :760-763).  Device `i` encodes shard `i` of the block partition `shard()` describes.
+pub struct MultiGpu {
+    h: *mut ffi::qoa_multi,
+    n_devices: usize,
+}
+unsafe impl Send for MultiGpu {}
+
+impl MultiGpu {
+    pub fn new(devices: &[i32]) -> Result<Self, EncodeError> {
+        let mut h = std::ptr::null_mut();
+        match unsafe { ffi::qoa_multi_create(devices.as_ptr(), devices.len() as c_int, &mut h) } {
+            0 => Ok(Self { h, n_devices: devices.len() }),
+            c => Err(enc_err(c)),
+        }
+    }
+    /// `(first, count)` of shard `index`
+    pub fn shard(&self, n_clips: usize, index: usize) -> (usize, usize) {
+        let (mut first, mut count) = (0usize, 0usize);
+        unsafe { ffi::qoa_multi_shard(n_clips, self.n_devices as c_int, index as c_int, &mut first, &mut count) };
+        (first, count)
+    }
+    /// # Safety
+    /// `pcm[i]` must be valid for every clip of shard `i` (host memory, or memory of device `i`), `out` for every clip's
+    /// `qoa_encoded_size` bytes at its `out_offset` (host memory, or memory of the first device).
+    pub unsafe fn encode(&mut self, clips: &[BatchClip], pcm: &[*const i16], out: *mut u8, chunk_frames: u32)
+                         -> Result<(), EncodeError> {
+        if pcm.len() != self.n_devices { return Err(EncodeError::InvalidSamples); }
+        let c: Vec<ffi::qoa_clip> = clips.iter().map(|c| ffi::qoa_clip {
+            pcm_offset: c.pcm_offset, out_offset: c.out_offset,
+            desc: ffi::qoa_desc { channels: c.desc.channels, sample_rate: c.desc.sample_rate, samples: c.desc.samples } }).collect();
+        match ffi::qoa_multi_encode(self.h, c.as_ptr(), c.len(), pcm.as_ptr(), out, chunk_frames) {
+            0 => Ok(()),
+            e => Err(enc_err(e)),
+        }
+    }
+    /// # Safety
+    /// as `encode`, with the roles of `enc` (one source for the batch) and `pcm[i]` (destination of shard `i`) swapped.
+    pub unsafe fn decode(&mut self, clips: &[BatchClip], enc: *const u8, pcm: &[*mut i16], chunk_frames: u32)
+                         -> Result<(), DecodeError> {
+        if pcm.len() != self.n_devices { return Err(DecodeError::InvalidFrameHeader); }
+        let c: Vec<ffi::qoa_clip> = clips.iter().map(|c| ffi::qoa_clip {
+            pcm_offset: c.pcm_offset, out_offset: c.out_offset,
+            desc: ffi::qoa_desc { channels: c.desc.channels, sample_rate: c.desc.sample_rate, samples: c.desc.samples } }).collect();
+        match ffi::qoa_multi_decode(self.h, c.as_ptr(), c.len(), enc, pcm.as_ptr(), chunk_frames) {
+            0 => Ok(()),
+            e => Err(dec_err(e)),
+        }
+    }
+}
+impl Drop for MultiGpu {
+    fn drop(&mut self) { unsafe { ffi::qoa_multi_free(self.h) } }
 }

@@ -172,7 +172,8 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
  *   out[3] slices the cheap-quotient step form declined (level from |quotient|, sign from the residual: exact unless a
  *          scalefactor-0/1 candidate's quotient wraps to the opposite sign; such a candidate is marked and must be beaten by
  *          a bound derived from the slice's samples, else the slice is repeated with the exact qoa_div -- loud passages);
- *   out[4] (wavefront, slice) pairs in which a candidate was marked at all (most are settled in place by the bound).
+ *   out[4] (wavefront, slice) pairs in which a candidate was marked at all (most are settled in place by the bound);
+ *   out[5] (wavefront, slice) pairs evaluated on the 32-bit / tail path, out[6] on the one-slice packed statement.
  * Entries beyond the last counter read 0. */
 int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n);
 

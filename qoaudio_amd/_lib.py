@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqoaudio_amd.so")
+# (QOAUDIO_AMD_LIB: development aid -- A/B timing of two builds of the library through the same Python harness)
+LIB_PATH = os.environ.get("QOAUDIO_AMD_LIB") or os.path.join(_HERE, "libqoaudio_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/qoaudio_amd.h declares (tests/test_capi_symbols.py checks the header against this)

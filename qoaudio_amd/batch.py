@@ -91,11 +91,12 @@ class EncodePlan:
             raise EncodeError(rc)
         return a.value, b.value, c.value
 
-    def counters(self) -> Tuple[int, int, int, int, int]:
-        """stats() + (slices the cheap-quotient step form declined, wavefront-slices in which it marked a candidate)
+    def counters(self) -> Tuple[int, ...]:
+        """stats() + (slices the cheap-quotient step form declined, wavefront-slices in which it marked a candidate,
+        wavefront-slices on the 32-bit / tail path, wavefront-slices on the one-slice packed statement)
         (qoa_encode_plan_counters)."""
-        out = (C.c_uint64 * 5)()
-        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 5)
+        out = (C.c_uint64 * 7)()
+        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 7)
         if rc:
             raise EncodeError(rc)
         return tuple(int(v) for v in out)

@@ -135,7 +135,7 @@ struct EncGroup {
     DevBuf lms;
 };
 
-constexpr size_t kCounters = 5; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
+constexpr size_t kCounters = 7; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
 struct qoa_encode_plan {
     std::vector<EncGroup *> groups;
     uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;

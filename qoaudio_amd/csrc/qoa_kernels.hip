@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             const unsigned tile_addr = (unsigned)(size_t)(lds_ptr)(tile + j * kSliceDwords);
             if (__builtin_amdgcn_ballot_w64(!(full && packed)) == 0ull) { // every chain of the wave can go packed
                 PkResult pr;
+                if (stats && lane == 0) atomicAdd(&stats[6], 1ull); // wavefront-slices on the one-slice packed statement
                 run_slice_pk(tile_addr, sf, kc, pk, pr);
                 if (__builtin_amdgcn_ballot_w64(pr.pen >= kPkPenLimit) == 0ull) { // all 64 candidates provably exact
                     const unsigned win = pick_winner(pr.e, pr.pen, pr.aerr0, sf);
@@ -719,6 +720,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 atomicAdd(&stats[1], 1ull); // (chain, slice) pairs on the 32-bit path because a state was not admissible
             }
             if (packed) pk_unpack(pk, st);
+            if (stats && lane == 0) atomicAdd(&stats[5], 1ull); // wavefront-slices on the 32-bit / tail path
 
             CandResult r;
             if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {

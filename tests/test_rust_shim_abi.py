@@ -11,7 +11,7 @@ from conftest import ROOT
 RS = os.path.join(ROOT, "bindings", "rust", "src", "qoaudio_mi355x.rs")
 HDR = os.path.join(ROOT, "include", "qoaudio_amd.h")
 
-RUST_SCALARS = {"u8": "uint8_t", "u16": "uint16_t", "u32": "uint32_t", "u64": "uint64_t", "i16": "int16_t", "i32": "int32_t",
+RUST_SCALARS = {"c_void": "void", "i64": "int64_t", "u8": "uint8_t", "u16": "uint16_t", "u32": "uint32_t", "u64": "uint64_t", "i16": "int16_t", "i32": "int32_t",
                 "usize": "size_t", "c_int": "int", "c_double": "double", "c_char": "char"}
 
 
@@ -55,10 +55,11 @@ def c_type(t):
                 base += " " + tok
     if arr:
         levels.append(("ptr", None))
-    # innermost pointee constness = base_const; deeper levels are mutable in this ABI
+    # level i (innermost = 0) is `*const` in Rust terms when what it points at is const: the base type for the innermost
+    # pointer, a `*const` pointer (C: `* const`) for the levels outside it
     out = []
     for i in range(len(levels)):
-        inner_const = base_const if i == 0 else False
+        inner_const = base_const if i == 0 else levels[i - 1][1] == "constptr"
         out.append("const" if inner_const else "mut")
     return base, list(reversed(out))  # outermost first
 
@@ -88,7 +89,10 @@ def parse_extern_block():
 
 def test_every_extern_symbol_matches_the_c_header():
     hdr, rs = parse_header(), parse_extern_block()
-    assert len(rs) >= 16
+    assert len(rs) >= 24
+    for name in ("qoa_decoder_new_reader", "qoa_multi_create", "qoa_multi_free", "qoa_multi_shard", "qoa_multi_encode",
+                 "qoa_multi_decode", "qoa_encode_batch_multi", "qoa_decode_batch_multi"):
+        assert name in rs, name
     for name, (ret, args) in rs.items():
         assert name in hdr, f"{name} is not declared in include/qoaudio_amd.h"
         c_ret, c_args = hdr[name]
@@ -125,14 +129,14 @@ def _struct_fields_rs(name):
 
 
 def test_repr_c_structs_match_the_header():
-    for name in ("qoa_desc", "qoa_frame_header", "qoa_mode", "qoa_item"):
+    for name in ("qoa_desc", "qoa_frame_header", "qoa_mode", "qoa_item", "qoa_clip"):
         c = [(n, t) for n, t in _struct_fields_c(name)]
         rs = _struct_fields_rs(name)
         assert [n for n, _ in c] == [n for n, _ in rs], (name, c, rs)
         for (_, ct), (_, rt) in zip(c, rs):
             assert ct == rt, (name, ct, rt)
     text = open(RS).read()
-    for name in ("qoa_desc", "qoa_frame_header", "qoa_mode", "qoa_item"):
+    for name in ("qoa_desc", "qoa_frame_header", "qoa_mode", "qoa_item", "qoa_clip"):
         assert re.search(r"#\[repr\(C\)\]\s*(#\[derive\([^)]*\)\]\s*)?pub struct " + name, text), name
 
 

@@ -16,13 +16,16 @@ samples = frames * 5120
 per = samples * ch
 enc = gpu.encoded_size(ch, samples)
 clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
-for kind in ("music", "white", "silence", "loud"):
+kinds = (os.environ.get("QOA_CLASSES") or "music,white,silence,loud").split(",")
+only_default = os.environ.get("QOA_DEFAULT_ONLY") == "1"
+for kind in kinds:
     if kind == "loud":  # the music class amplified 3x into clipping
         pcm = (synth.make_clips(n_clips, samples, ch, 44100, device="cuda").to(torch.int32) * 3).clamp_(-32768, 32767).to(torch.int16)
     else:
         pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda", kind=kind)
     ref = None
-    for name, fl in (("default", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT), ("no speculation", batch.PLAN_NO_SPECULATION)):
+    for name, fl in ((("default", 0),) if only_default else
+                     (("default", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT), ("no speculation", batch.PLAN_NO_SPECULATION))):
         plan = batch.EncodePlan(clips, fl | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm.view(-1), out)
