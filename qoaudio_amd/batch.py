@@ -20,6 +20,7 @@ PLAN_NO_SPECULATION = 4
 PLAN_LDS_TABLES = 8
 PLAN_NO_LDS_TABLES = 128
 PLAN_EXACT_QUOTIENT = 256
+PLAN_NO_PENALTY_FORM = 1024
 PLAN_COUNTERS = 512  # count the fast paths' fall-backs (EncodePlan.stats / .counters); off by default: no atomics in the kernel
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 
@@ -93,10 +94,11 @@ class EncodePlan:
 
     def counters(self) -> Tuple[int, ...]:
         """stats() + (slices the cheap-quotient step form declined, wavefront-slices in which it marked a candidate,
-        wavefront-slices on the 32-bit / tail path, wavefront-slices on the one-slice packed statement)
+        wavefront-slices on the 32-bit / tail path, wavefront-slices on the one-slice packed statement, slices the
+        penalty form declined)
         (qoa_encode_plan_counters)."""
-        out = (C.c_uint64 * 7)()
-        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 7)
+        out = (C.c_uint64 * 8)()
+        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 8)
         if rc:
             raise EncodeError(rc)
         return tuple(int(v) for v in out)

@@ -340,6 +340,35 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
     return done;
 }
 
+// The penalty form (QOA_BLOCK_PEN_ASM_TEXT, tools/gen_slice_asm.py: pk_block(pen=True)): cheap-quotient steps WITH the penalty
+// arithmetic on every step; the rank is err^2 + penalty as the full form's, nothing about the penalty is speculated.  What
+// the block loop runs where the speculative forms miss (winners that carry a penalty: tonal passages) -- 27 instead of the
+// full form's 35 instructions per step.  Declines (done < n, entry state restored) like run_block_spec<true> (marked
+// candidate not provably a loser, rank not provably exact) and like run_block_pk (a candidate's weight energy left the
+// packed window: penalty sum >= kPkPenLimit).
+__device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
+                                                  int sf, const StepConst &k, unsigned n, PkLms &pk) {
+    register unsigned w01 asm("v84") = pk.w01;
+    register unsigned w23 asm("v85") = pk.w23;
+    register unsigned pa asm("v86") = pk.pa;
+    register unsigned pb asm("v87") = pk.pb;
+    unsigned done, marks;
+    asm volatile(QOA_BLOCK_PEN_ASM_TEXT
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [marks] "=&s"(marks)
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
+                   [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),
+                   [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp), [limit] "s"(kPkPenLimit)
+                 : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+                   "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+                   "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                   "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+                   "v124", "v125", "v126", "v127");
+    (void)marks;
+    pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
+    return done;
+}
+
 // run_block_spec with the quantiser / dequantiser in an LDS table (QOA_BLOCK_SPEC_LDSQ_ASM_TEXT, tools/gen_slice_asm.py:
 // pk_step_ldsq): 22 VALU + 1 LDS read per step instead of 30 VALU.  `qtab` = LDS byte address of this lane's table entry for
 // scaled = 0 (entries for scaled = -8..8 sit at qtab - 32 .. qtab + 32).  Used when the launch gives every SIMD several
@@ -574,12 +603,18 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const bool allow_spec = (flags & 8u) == 0;   // bit 3: no speculative (penalty-free) steps
     const bool lds_tables = (flags & 16u) != 0;  // bit 4: speculative steps look the quantiser up in LDS (full-chip launches)
     const bool allow_cheap = (flags & 32u) == 0; // bit 5: no cheap-quotient steps
+    const bool allow_pen = (flags & 64u) == 0 && allow_cheap && allow_spec && !lds_tables; // bit 6: no penalty form
     const unsigned qtab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_qtab[sf][8];
     int limq, winq;
     spec_limits(sf, limq, winq);
     unsigned spec_cooldown = 0;  // blocks left on the full form after a speculation miss (wave-uniform)
     unsigned cheap_cooldown = 0; // blocks left on the exact-quotient speculative form after the cheap one declined slices
     unsigned last_cheap_decline = 0xfffffff0u; // block of the cheap form's last decline (wave-uniform)
+    // Consecutive attempt blocks in which the speculative forms / the penalty form had to hand a slice on (wave-uniform).
+    // From the second one in a row the form sits out, 4 blocks at first and twice as long each further time up to 64:
+    // material that defeats a form does so for long stretches (tonal passages keep the weights at the penalty threshold for
+    // seconds; full-scale noise and clipped material never leave it), an isolated miss costs the rest of its block only.
+    unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0;
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -678,9 +713,25 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                         }
                     }
                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: all forms return an SGPR)
-                    if (j < kBlockSlices) { // slice j could not be proven: the full form takes over, here and for a while
-                        spec_cooldown = kSpecCooldownBlocks + 1;
+                    if (j < kBlockSlices) { // slice j could not be proven: the penalty / full form takes over for the rest of the block
+                        spec_streak = min(spec_streak + 1u, 6u);
+                        if (spec_streak >= 2u) spec_cooldown = (kSpecCooldownBlocks << (spec_streak - 2u)) + 1;
                         if (stats && sf == 0) atomicAdd(&stats[2], 1ull);
+                    } else {
+                        spec_streak = 0;
+                    }
+                }
+                if (j < kBlockSlices && allow_pen && pen_cooldown == 0) {
+                    // where the speculation missed (and while it sits out): cheap-quotient steps with the penalty arithmetic
+                    const unsigned r = run_block_pen(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j, dummy_addr,
+                                                     sf, kc, kBlockSlices - j, pk);
+                    j += (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+                    if (j < kBlockSlices) { // declined (loud material, weights beyond the packed window): the full form goes on
+                        pen_streak = min(pen_streak + 1u, 6u);
+                        if (pen_streak >= 2u) pen_cooldown = (kSpecCooldownBlocks << (pen_streak - 2u)) + 1;
+                        if (stats && sf == 0) atomicAdd(&stats[7], 1ull);
+                    } else {
+                        pen_streak = 0;
                     }
                 }
                 if (j < kBlockSlices) {
@@ -691,6 +742,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             }
             if (spec_cooldown) spec_cooldown--;
             if (cheap_cooldown) cheap_cooldown--;
+            if (pen_cooldown) pen_cooldown--;
         }
         for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);

@@ -533,7 +533,8 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     clips = [(0, 0, gpu.QoaDesc(2, 44100, n))]
     pcm = torch.from_numpy(fixture_pcm).cuda()
     outs = []
-    for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT):
+    for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT,
+                  batch.PLAN_NO_PENALTY_FORM):
         plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
@@ -556,9 +557,11 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
             assert 0 < misses <= 2 * ((n + 19) // 20) // 20  # tonal passages: a few per cent, never the bulk
         elif flags == batch.PLAN_NO_SPECULATION:
             assert misses == 0 and declined + unpacked <= 2 * ((n + 19) // 20) // 200
+        elif flags == batch.PLAN_NO_PENALTY_FORM:
+            assert plan.counters()[7] == 0 and 0 < misses <= 2 * ((n + 19) // 20) // 20
         else:
             assert (declined, unpacked, misses) == (0, 0, 0)
-    assert outs[0] == outs[1] == outs[2] == outs[3] == oracle.encode_all(fixture_pcm, 2, 44100, n)
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4] == oracle.encode_all(fixture_pcm, 2, 44100, n)
 
 
 @pytest.mark.parametrize("gain", [1.5, 3.0, 8.0])

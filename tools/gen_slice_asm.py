@@ -140,10 +140,14 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     # Speculative form (spec): no penalty arithmetic at all; the weight energy is only sampled, at every 4th step, into a
     # running maximum that the block loop tests after the slice (see pk_block).  Its samples stay i16 pairs and its rank is
     # a saturating 32-bit sum formed two steps at a time (spec_rank_pair).
-    pen_full = not spec
-    check = spec and i % 4 == 0
+    # Penalty form (N["pen_steps"], round 3): the cheap-quotient speculative step WITH the penalty arithmetic of the full form
+    # -- for the stretches where the speculation's premise (a penalty-free winner) does not hold: see pk_block.
+    pen_steps = bool(N.get("pen_steps"))
+    pen_full = not spec or pen_steps
+    check = spec and not pen_steps and i % 4 == 0
     cheap = bool(N.get("cheap"))
     A1 = CH_A1[i % 2]
+    PT = X if not pen_steps else PEN_TMP[i % 2]            # penalty temporary (the cheap steps keep X for their flag OR)
     L = [
         f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
         f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]" if pen_full or check else None,   # sum w^2 - (0x8ff << 18)
@@ -153,13 +157,13 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         slot_a,
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",  # (+-1, +-1) for B_n
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
-        f"v_ashrrev_i32 {X}, 18, {Q}" if pen_full else None,
+        f"v_ashrrev_i32 {PT}, 18, {Q}" if pen_full else None,
         sub_t,
         slot_b,
-        f"v_max_i32 {X}, 0, {X}" if pen_full else None,     # penalty
+        f"v_max_i32 {PT}, 0, {PT}" if pen_full else None,   # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1" if not cheap else f"v_ashrrev_i32 {SN}, 31, {T}",
-        f"v_mad_i32_i24 {pen}, {X}, {X}, {pen}" if pen_full else None,
+        f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}" if pen_full else None,
         (f"v_mov_b32 {N['qm']}, {Q}" if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
         f"v_ashrrev_i32 {U}, 16, {U}" if not cheap else None,
     ] + ([
@@ -221,7 +225,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
-        assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (2 if i % 2 == 0 else 0)
+        assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0)
         if i == 2:
             k = L.index(slot_b) + 1
             L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
@@ -359,6 +363,7 @@ BOUND_IN = f"v{SPK0 - 2}"
 # extra fixed registers of the cheap-quotient form (v96..v103 are free in the speculative forms: no widened samples)
 CH_W, CH_TMP, CH_BIG, CH_BND = "v96", "v97", "v98", "v99"
 CH_A1 = ["v100", "v101"]   # +-1 of the residual's sign, per temporary set
+PEN_TMP = ["v102", "v103"]  # penalty form: the penalty of a step, per temporary set
 
 
 def unpack_samples():
@@ -500,7 +505,7 @@ def schedule(lines):
     return order, back_to_back
 
 
-def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
+def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -519,7 +524,16 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
       the winner         QM < %[winq]   (its penalty was zero at all 20 steps, so its rank is its true rank, and every
                                          other candidate's true rank is at least its computed one: same winner).
     The second test comes after the election, when this slice's candidates already sit in the LDS slots; the slots are
-    therefore double-buffered (%[pp] = byte distance) so that the entry state is still there for a late exit."""
+    therefore double-buffered (%[pp] = byte distance) so that the entry state is still there for a late exit.
+
+    pen=True (with spec and cheap) is the PENALTY form: the cheap-quotient speculative step plus the full form's penalty
+    arithmetic on every step (27 instructions + the rank pair every second step).  Nothing is speculated about the
+    penalty: the rank the election sees is the saturating err^2 sum plus the penalty sum, exact whenever it is below
+    32767^2 (then so is its err^2 part); the exactness of the i16 arithmetic is the full form's test, penalty sum <
+    %[limit] for all 64 candidates.  No energy sampling, no winner test after the election.  It is what the block loop
+    falls back to where the speculative forms miss -- tonal passages, whose winners carry a penalty (3 % of real music's
+    slices, clustered) -- instead of the 35-instruction full form."""
+    assert not pen or (spec and cheap and not ldsq)
     N = dict(PK_FIXED, **SPEC_REGS) if spec else PK_FIXED
     assert not spec or (N["R"][3], N["RC"][1], PK_S[2], PK_S[3]) == ("v92", "v93", "v94", "v95")   # = SLOT2
     K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"   # K1/M/K2 share the dot registers (long dead by now)
@@ -551,12 +565,12 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         "Lqoa_top_%=:",
         # the winner's state; a slice-word store may trail, and in the speculative loops SLOT2's read (waited for below)
         f"s_waitcnt lgkmcnt({2 if spec else 1})",
-    ]
+    ] + ([f"v_mov_b32 {N['pen']}, 0"] if pen else [])
     body = [] if spec else pk_prologue(N, zero=False)        # rank and penalty sums are cleared in the election's gaps
     if ldsq:
         N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
     elif spec:
-        N = dict(N, fill=FILL, cheap=cheap)
+        N = dict(N, fill=FILL, cheap=cheap, pen_steps=pen)
     acc_line = None
     for i in range(20):
         if ldsq:
@@ -577,7 +591,10 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
         E = N["alt"][8]                                      # pair 9: the odd pairs' register (pk_step)
         body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,       # the last error pair (spec_rank_pair)
                  f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL,
-                 f"v_cmp_ge_i32 vcc, {QM}, %[limq]" + FILL]    # the first test below, as one more filler
+                 # the first test below, as one more filler
+                 (f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]" if pen else f"v_cmp_ge_i32 vcc, {QM}, %[limq]") + FILL]
+        if pen:   # total rank = err^2 sum + penalty sum (both < 2^31: no carry); scheduled, so the v_dot2 wait states hold
+            body.append(f"v_add_u32 {ELO}, {ELO}, {N['pen']}")
         if cheap:
             body.append(f"v_mov_b32 {CH_BND}, s94" + FILL)   # the winner's rank limit when no candidate is marked
     if ldsq:
@@ -647,11 +664,12 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False):
     ] + ([f"ds_read_b128 {SLOT2}, {ADDR} offset:16"] if spec else []) + ["s_nop 0"] * int(os.environ.get("QOA_GEN_NOPS_BEHIND_STATE_READ", "0")) + [   # (experiment: how long is the read exposed?)
         f"v_cmp_eq_u32 vcc, {ADDR}, {cand}",
         f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
-    ] + ([f"v_cndmask_b32 {THR}, %[limq], %[winq], vcc"] if spec else []) + [   # non-winners: the test they already passed
+    ] + ([f"v_cndmask_b32 {THR}, %[limq], %[winq], vcc"] if spec and not pen else []) + [   # non-winners: the test they already passed
         f"ds_write_b64 {OADDR}, v[80:81]",
     ] + ([
         f"v_cmp_ge_i32 vcc, {QM}, {THR}",                    # can only fire in the winner's lane
         "s_cbranch_vccnz Lqoa_late_%=",
+    ] if spec and not pen else []) + ([
         f"v_mov_b32 {PADDR}, {ADDR}",                        # this slice is final: its winner's slot holds the next entry state
     ] if spec else []) + [
         "s_cbranch_scc1 Lqoa_top_%=",
@@ -688,6 +706,7 @@ def render(verbose=False):
     blk_spec = pk_block(verbose, spec=True)
     blk_ldsq = pk_block(verbose, spec=True, ldsq=True)
     blk_cheap = pk_block(verbose, spec=True, cheap=True)
+    blk_pen = pk_block(verbose, spec=True, cheap=True, pen=True)
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
@@ -702,8 +721,11 @@ def render(verbose=False):
            + emit("QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", blk_ldsq) + "\n"
            + "// QOA_BLOCK_CHEAP_ASM_TEXT: the speculative loop with the cheap quotient (22/25 VALU per step; level from |n|, sign\n"
            + "//   from the residual, candidates whose quotient wrapped to the opposite sign are marked and proven losers).\n"
-           + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap))
-    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap))
+           + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap) + "\n"
+           + "// QOA_BLOCK_PEN_ASM_TEXT: the cheap-quotient loop WITH the penalty arithmetic on every step (27/step): what the\n"
+           + "//   block loop falls back to where the speculative forms miss (winners that carry a penalty), before the full form.\n"
+           + emit("QOA_BLOCK_PEN_ASM_TEXT", blk_pen))
+    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap), len(blk_pen))
 
 
 INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")

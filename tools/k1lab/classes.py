@@ -19,13 +19,22 @@ clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_cl
 kinds = (os.environ.get("QOA_CLASSES") or "music,white,silence,loud").split(",")
 only_default = os.environ.get("QOA_DEFAULT_ONLY") == "1"
 for kind in kinds:
-    if kind == "loud":  # the music class amplified 3x into clipping
+    if kind == "fixture":  # clips cut from the decoded reference fixture at offsets spread over the whole song
+        import numpy as np
+        from oracle import oracle as O
+        _, _, fp = O.decode_all(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden",
+                                                  "julien_baker_sprained_ankle.qoa"), "rb").read())
+        song = torch.from_numpy(fp.reshape(-1, 2))
+        offs = (np.arange(n_clips) * 997 * 20) % (song.shape[0] - samples)
+        pcm = torch.stack([song[o:o + samples] for o in offs]).cuda().contiguous()
+    elif kind == "loud":  # the music class amplified 3x into clipping
         pcm = (synth.make_clips(n_clips, samples, ch, 44100, device="cuda").to(torch.int32) * 3).clamp_(-32768, 32767).to(torch.int16)
     else:
         pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda", kind=kind)
     ref = None
     for name, fl in ((("default", 0),) if only_default else
-                     (("default", 0), ("exact quotient", batch.PLAN_EXACT_QUOTIENT), ("no speculation", batch.PLAN_NO_SPECULATION))):
+                     (("default", 0), ("no penalty form", batch.PLAN_NO_PENALTY_FORM), ("exact quotient", batch.PLAN_EXACT_QUOTIENT),
+                      ("no speculation", batch.PLAN_NO_SPECULATION))):
         plan = batch.EncodePlan(clips, fl | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm.view(-1), out)
