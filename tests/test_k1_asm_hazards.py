@@ -83,7 +83,7 @@ def check(name, lines):
 def test_every_text_keeps_the_wait_states():
     t = texts()
     assert set(t) >= {"QOA_SLICE_ASM_TEXT", "QOA_SLICE_PK_ASM_TEXT", "QOA_BLOCK_PK_ASM_TEXT", "QOA_BLOCK_SPEC_ASM_TEXT",
-                      "QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", "QOA_BLOCK_CHEAP_ASM_TEXT"}
+                      "QOA_BLOCK_SPEC_LDSQ_ASM_TEXT", "QOA_BLOCK_CHEAP_ASM_TEXT", "QOA_BLOCK_PEN_ASM_TEXT"}
     for name, lines in t.items():
         assert len(lines) > 400, name
         check(name, lines)

@@ -165,3 +165,14 @@ def test_public_signatures_equal_the_reference():
     ):
         assert sig in text, sig
     # (`into_inner(mut self)` / `decode_all(mut reader)`: `mut` on a by-value binding is not part of a signature)
+
+
+def test_integration_md_excerpts_are_verbatim():
+    """INTEGRATION.md section 2 quotes the shim instead of restating it: every ```rust block there must be a verbatim run of
+    lines of bindings/rust/src/qoaudio_mi355x.rs (the document went stale once when it carried its own copy)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rs = open(RS).read()
+    blocks = re.findall(r"```rust\n(.*?)\n```", doc, re.S)
+    assert len(blocks) >= 5
+    for b in blocks:
+        assert b in rs, b[:200]

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-2 profile set (run on the GPU box through gpurun): PMC passes on the standalone driver, memory-path counters,
-# and the rocprofv3 kernel trace of the very command the driver runs (bench.py).  Everything lands in gpurun_out/<tag>*.
+# A round's profile set (run on the GPU box through gpurun): PMC passes on the standalone driver, memory-path counters,
+# and the rocprofv3 kernel trace of the very command the driver runs (bench.py).  Everything lands in gpurun_out/<tag>*;
+# tools/refresh_profiles.py <round> <tag> copies what is committed under profiles/.
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-prof}
 bash tools/pmc.sh ${TAG}_pmc > gpurun_out/${TAG}_pmc.log 2>&1
 bash tools/pmc_mem.sh ${TAG}_pmc_mem > gpurun_out/${TAG}_pmc_mem.log 2>&1
 mkdir -p gpurun_out/${TAG}_trace
