@@ -561,7 +561,6 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
         pk_prologue(N, zero=False, spec=True) if spec else []) + [   # speculative loops: once per call; then SLOT2 carries it
         "s_mov_b32 %[done], 0",
         "s_waitcnt lgkmcnt(0)",
-    ] + ([f".p2align {os.environ['QOA_GEN_ALIGN_TOP']}"] if os.environ.get("QOA_GEN_ALIGN_TOP") else []) + [
         "Lqoa_top_%=:",
         # the winner's state; a slice-word store may trail, and in the speculative loops SLOT2's read (waited for below)
         f"s_waitcnt lgkmcnt({2 if spec else 1})",
