@@ -219,7 +219,9 @@ int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, const uint8_t *
  *           every out_offset counts from it.  A shard's encoded bytes travel to `out` slice by slice while the next slice
  *           is being encoded (peer copies over xGMI when `out` is on the root): that IS the gather of the encoded streams.
  *   decode: `enc` is ONE source (host or root memory, out_offset counts from it), pcm[i] the destination base of shard i.
- * Memory of any other device is legal wherever the HIP runtime can copy from / to it.  Synchronous: complete on return.
+ * A shard's PCM / the output that already sits in the memory of the device that works on it is used in place (no staging
+ * copy; offsets into device memory must then be 8-byte aligned for the encoded side); memory of any other device is legal
+ * wherever the HIP runtime can copy from / to it.  Synchronous: complete on return.
  * Errors: a device ordinal that does not exist or is listed twice, and every HIP failure (peer access included), return
  * the IoError code with qoa_last_error_detail() naming the device; nothing aborts. */
 typedef struct qoa_multi qoa_multi;

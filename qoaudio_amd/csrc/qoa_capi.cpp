@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -338,6 +339,16 @@ struct PipeDrain {
     }
 };
 
+// Is `p` memory of the calling thread's current device?  (Then a pipeline stage that would only copy it to a staging
+// buffer on the same device is skipped: the kernels read / write it in place.)  Plain host memory is unknown to the runtime.
+static bool on_current_device(const void *p) {
+    hipPointerAttribute_t a;
+    int cur = -1;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    return a.type == hipMemoryTypeDevice && a.device == cur;
+}
+
 static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
                             uint32_t chunk_frames) {
     if (!clips || !h_pcm || !h_out) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
@@ -348,7 +359,16 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
         if (rc) return rc;
         max_frames = std::max<uint32_t>(max_frames, (clips[i].desc.samples + kFrameLen - 1) / kFrameLen);
     }
-    const uint32_t F = chunk_frames ? chunk_frames : 8; // config 3: 102.1 ms at 8 or 4 frames, 104.9 at 16, 111.3 at 32
+    // qoa_multi_*: a shard whose PCM / output already sits in this device's memory is used in place (no staging copy in /
+    // out); with both in place there is nothing to overlap and the batch is one launch
+    const bool src_direct = on_current_device(h_pcm), dst_direct = on_current_device(h_out);
+    if (dst_direct) { // the kernel stores 8-byte words straight into the caller's buffer
+        if ((uintptr_t)h_out % 8 != 0) return fail_msg("device output base must be 8-byte aligned", QOA_ENCODE_IO_ERROR);
+        for (size_t i = 0; i < n_clips; i++)
+            if (clips[i].out_offset % 8 != 0) return fail_msg("qoa_clip.out_offset must be 8-byte aligned", QOA_ENCODE_IO_ERROR);
+    }
+    uint32_t F = chunk_frames ? chunk_frames : 8; // config 3: 102.1 ms at 8 or 4 frames, 104.9 at 16, 111.3 at 32
+    if (src_direct && dst_direct) F = max_frames;
     const uint32_t n_chunks = (max_frames + F - 1) / F;
 
     // device staging layout: per clip a PCM region of F frames and an encoded region of 8 + F frames, per buffer
@@ -376,8 +396,8 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
     size_t n_chains_total = 0;
     for (size_t i = 0; i < n_clips; i++) n_chains_total += clips[i].desc.channels;
     for (int b = 0; b < 2; b++) {
-        HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_ENCODE_IO_ERROR);
-        HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_ENCODE_IO_ERROR);
+        if (!src_direct) HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_ENCODE_IO_ERROR);
+        if (!dst_direct) HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_ENCODE_IO_ERROR);
         HIP_TRY(P.chains[b].reserve(n_chains_total * sizeof(EncChain)), QOA_ENCODE_IO_ERROR);
     }
     HIP_TRY(P.lms.reserve(n_chains_total * 8 * sizeof(int32_t)), QOA_ENCODE_IO_ERROR);
@@ -403,19 +423,21 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                     const uint64_t first = (uint64_t)j * F * kFrameLen;
                     const uint32_t now = d.samples > first ? (uint32_t)std::min<uint64_t>(d.samples - first, (uint64_t)F * kFrameLen) : 0;
                     qoa_clip c;
-                    c.pcm_offset = pcm_reg[i];
-                    c.out_offset = enc_reg[i];
+                    c.pcm_offset = src_direct ? clips[i].pcm_offset + first * d.channels : pcm_reg[i];
+                    // in place the slice continues where the one before ended: file header + the frames so far
+                    c.out_offset = !dst_direct ? enc_reg[i]
+                                   : clips[i].out_offset + (j == 0 ? 0 : 8 + (uint64_t)j * F * qoa_frame_size(d.channels, kSlicesPerFrame));
                     c.desc = d;
                     make_chains(c, j == 0, now, table[b]);
                     gb += d.channels;
-                    if (now && !uniform)
+                    if (now && !uniform && !src_direct)
                         HIP_TRY(hipMemcpyAsync((int16_t *)P.pcm[b].p + pcm_reg[i], h_pcm + clips[i].pcm_offset + first * d.channels,
                                                (size_t)now * d.channels * 2, hipMemcpyDefault, P.s_in),
                                 QOA_ENCODE_IO_ERROR);
                 }
             }
             group_begin[kMaxChannels + 1] = gb;
-            if (uniform) {
+            if (uniform && !src_direct) {
                 const qoa_desc &d = clips[0].desc;
                 const uint64_t first = (uint64_t)j * F * kFrameLen;
                 const uint32_t now = (uint32_t)std::min<uint64_t>(d.samples - first, (uint64_t)F * kFrameLen);
@@ -434,14 +456,15 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
             for (int nch = 1; nch <= kMaxChannels; nch++) {
                 const unsigned n = (nch < kMaxChannels ? group_begin[nch + 1] : group_begin[kMaxChannels + 1]) - group_begin[nch];
                 if (!n) continue;
-                HIP_TRY(launch_encode(pick_cpw(n, 0), nch, (const int16_t *)P.pcm[b].p, (uint8_t *)P.enc[b].p,
+                HIP_TRY(launch_encode(pick_cpw(n, 0), nch, src_direct ? h_pcm : (const int16_t *)P.pcm[b].p,
+                                      dst_direct ? h_out : (uint8_t *)P.enc[b].p,
                                       (const EncChain *)P.chains[b].p + group_begin[nch], n,
                                       (int32_t *)P.lms.p + (size_t)group_begin[nch] * 8, j == 0 ? 2u : 0u, nullptr, P.s_k),
                         QOA_ENCODE_IO_ERROR);
             }
             HIP_TRY(hipEventRecord(P.k_done[b], P.s_k), QOA_ENCODE_IO_ERROR);
         }
-        if (j >= 1) {
+        if (j >= 1 && !dst_direct) {
             // ---- stage out: encoded bytes of time slice j-1 ----
             const uint32_t jj = j - 1;
             const int bo = (int)(jj & 1u);
@@ -1032,7 +1055,15 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
         if (validate_desc(&clips[i].desc)) return fail_msg("invalid qoa_desc in decode batch", QOA_DECODE_INVALID_FRAME_HEADER);
         max_frames = std::max<uint32_t>(max_frames, (clips[i].desc.samples + kFrameLen - 1) / kFrameLen);
     }
-    const uint32_t F = chunk_frames ? chunk_frames : 8;
+    // (as in host_pipe_encode: memory of this device is used in place)
+    const bool src_direct = on_current_device(h_enc), dst_direct = on_current_device(h_pcm);
+    if (src_direct) { // the kernels read frames in place with 8-byte loads
+        if ((uintptr_t)h_enc % 8 != 0) return fail_msg("device stream base must be 8-byte aligned", QOA_DECODE_IO_ERROR);
+        for (size_t i = 0; i < n_clips; i++)
+            if (clips[i].out_offset % 8 != 0) return fail_msg("encoded offset must be 8-byte aligned", QOA_DECODE_IO_ERROR);
+    }
+    uint32_t F = chunk_frames ? chunk_frames : 8;
+    if (src_direct && dst_direct) F = max_frames;
     const uint32_t n_chunks = (max_frames + F - 1) / F;
     HIP_TRY(P.init(), QOA_DECODE_IO_ERROR);
     PipeDrain drain{P};
@@ -1057,8 +1088,8 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
               clips[1].pcm_offset - clips[0].pcm_offset >= (uint64_t)clips[0].desc.samples * clips[0].desc.channels &&
               clips[1].out_offset - clips[0].out_offset >= qoa_encoded_size(clips[0].desc.channels, clips[0].desc.samples);
     for (int b = 0; b < 2; b++) {
-        HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_DECODE_IO_ERROR);
-        HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_DECODE_IO_ERROR);
+        if (!dst_direct) HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_DECODE_IO_ERROR);
+        if (!src_direct) HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_DECODE_IO_ERROR);
     }
     // what time slice j holds of clip d: frames, encoded bytes (whole frames, the last one possibly short), sample-times
     auto slice_of = [&](const qoa_desc &d, uint32_t j, uint64_t *enc_off, uint64_t *enc_bytes, uint64_t *first, uint64_t *now) {
@@ -1083,10 +1114,11 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 uint64_t eo, eb, first, now;
                 slice_of(d, j, &eo, &eb, &first, &now);
                 if (!now) continue;
-                if (!uniform)
+                if (!uniform && !src_direct)
                     HIP_TRY(hipMemcpyAsync((uint8_t *)P.enc[b].p + enc_reg[i], h_enc + clips[i].out_offset + eo, eb,
                                            hipMemcpyDefault, P.s_in), QOA_DECODE_IO_ERROR);
-                uint64_t pos = enc_reg[i], outp = pcm_reg[i], left = now;
+                uint64_t pos = src_direct ? clips[i].out_offset + eo : enc_reg[i];
+                uint64_t outp = dst_direct ? clips[i].pcm_offset + first * d.channels : pcm_reg[i], left = now;
                 while (left > 0) {
                     const uint32_t fl = (uint32_t)std::min<uint64_t>(left, kFrameLen);
                     const uint32_t rows = (fl + kSliceLen - 1) / kSliceLen;
@@ -1100,7 +1132,7 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                     pos += fsize; outp += (uint64_t)fl * d.channels; left -= fl;
                 }
             }
-            if (uniform) {
+            if (uniform && !src_direct) {
                 uint64_t eo, eb, first, now;
                 slice_of(clips[0].desc, j, &eo, &eb, &first, &now);
                 HIP_TRY(hipMemcpy2DAsync(P.enc[b].p, enc_reg[1] - enc_reg[0], h_enc + clips[0].out_offset + eo,
@@ -1116,10 +1148,11 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
             // ---- decode time slice j (its PCM buffer is free once slice j-2 has been copied out) ----
             HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0), QOA_DECODE_IO_ERROR);
             if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0), QOA_DECODE_IO_ERROR);
-            HIP_TRY(T.run((const uint8_t *)P.enc[b].p, (int16_t *)P.pcm[b].p, P.s_k, false), QOA_DECODE_IO_ERROR);
+            HIP_TRY(T.run(src_direct ? h_enc : (const uint8_t *)P.enc[b].p, dst_direct ? h_pcm : (int16_t *)P.pcm[b].p, P.s_k, false),
+                    QOA_DECODE_IO_ERROR);
             HIP_TRY(hipEventRecord(P.k_done[b], P.s_k), QOA_DECODE_IO_ERROR);
         }
-        if (j >= 1) {
+        if (j >= 1 && !dst_direct) {
             // ---- stage out: PCM of time slice j-1 ----
             const uint32_t jj = j - 1;
             const int bo = (int)(jj & 1u);
