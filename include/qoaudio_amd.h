@@ -136,6 +136,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_NO_LDS_TABLES 128u    /*        default: only in launches with >= 8 wavefronts per SIMD) / in none */
 #define QOA_PLAN_EXACT_QUOTIENT 256u   /* debug: speculative steps always with the exact qoa_div fix-up (same bytes) */
 #define QOA_PLAN_NO_PENALTY_FORM 1024u /* debug: where the speculative steps miss, go straight to the full form (same bytes) */
+#define QOA_PLAN_NO_BLOCK32 2048u       /* debug: slices the packed forms cannot take go one by one, not through the 32-bit block loop */
 #define QOA_PLAN_COUNTERS 512u         /* count the fast paths' fall-backs (qoa_encode_plan_stats / _counters); without it the */
                                        /* kernel is handed no counter block and executes no atomic at all */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
@@ -174,7 +175,7 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
  *          scalefactor-0/1 candidate's quotient wraps to the opposite sign; such a candidate is marked and must be beaten by
  *          a bound derived from the slice's samples, else the slice is repeated with the exact qoa_div -- loud passages);
  *   out[4] (wavefront, slice) pairs in which a candidate was marked at all (most are settled in place by the bound);
- *   out[5] (wavefront, slice) pairs evaluated on the 32-bit / tail path, out[6] on the one-slice packed statement;
+ *   out[5] (wavefront, slice) pairs evaluated on the 32-bit step (block statement, one-slice statement or tail path), out[6] on the one-slice packed statement;
  *   out[7] slices the penalty form (cheap-quotient steps with the penalty arithmetic: the fall-back for speculation
  *          misses) declined and handed to the full form.
  * Entries beyond the last counter read 0. */

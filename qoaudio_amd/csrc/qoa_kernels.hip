@@ -369,6 +369,36 @@ __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned c
     return done;
 }
 
+// `n` consecutive full slices on the 32-bit step in ONE statement (QOA_BLOCK_32_ASM_TEXT, tools/gen_slice_asm.py: b32_block):
+// full i32 weights, so it cannot decline -- the block loop's last resort for wavefronts with a chain whose state, or whose
+// losing candidates, leave the packed forms' window slice after slice.  Election and state exchange as in run_block_pk, with
+// both halves of the 32-byte slot (history, weights).
+__device__ __forceinline__ void run_block_32(unsigned tile_addr, unsigned cand, unsigned outb, unsigned dummy, int sf,
+                                             const StepConst &k, unsigned n, Lms &st) {
+    register int h0 asm("v84") = st.h0;
+    register int h1 asm("v85") = st.h1;
+    register int h2 asm("v86") = st.h2;
+    register int h3 asm("v87") = st.h3;
+    register int w0 asm("v88") = st.w0;
+    register int w1 asm("v89") = st.w1;
+    register int w2 asm("v90") = st.w2;
+    register int w3 asm("v91") = st.w3;
+    unsigned done;
+    asm volatile(QOA_BLOCK_32_ASM_TEXT
+                 : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), [done] "=&s"(done)
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
+                   [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [n] "s"(n),
+                   [mf0] "s"(0x1e0)
+                 : "vcc", "scc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v92",
+                   "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+                   "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
+                   "v122", "v123", "v124", "v125", "v126", "v127");
+    (void)done;
+    st.h0 = h0; st.h1 = h1; st.h2 = h2; st.h3 = h3;
+    st.w0 = w0; st.w1 = w1; st.w2 = w2; st.w3 = w3;
+}
+
 // run_block_spec with the quantiser / dequantiser in an LDS table (QOA_BLOCK_SPEC_LDSQ_ASM_TEXT, tools/gen_slice_asm.py:
 // pk_step_ldsq): 22 VALU + 1 LDS read per step instead of 30 VALU.  `qtab` = LDS byte address of this lane's table entry for
 // scaled = 0 (entries for scaled = -8..8 sit at qtab - 32 .. qtab + 32).  Used when the launch gives every SIMD several
@@ -604,6 +634,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const bool lds_tables = (flags & 16u) != 0;  // bit 4: speculative steps look the quantiser up in LDS (full-chip launches)
     const bool allow_cheap = (flags & 32u) == 0; // bit 5: no cheap-quotient steps
     const bool allow_pen = (flags & 64u) == 0 && allow_cheap && allow_spec && !lds_tables; // bit 6: no penalty form
+    const bool allow_b32 = (flags & 128u) == 0;  // bit 7: no 32-bit block statement (slices the packed forms decline go one by one)
     const unsigned qtab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_qtab[sf][8];
     int limq, winq;
     spec_limits(sf, limq, winq);
@@ -614,7 +645,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // From the second one in a row the form sits out, 4 blocks at first and twice as long each further time up to 64:
     // material that defeats a form does so for long stretches (tonal passages keep the weights at the penalty threshold for
     // seconds; full-scale noise and clipped material never leave it), an isolated miss costs the rest of its block only.
-    unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0;
+    unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0, pk_cooldown = 0, pk_streak = 0;
 
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
@@ -678,11 +709,13 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         const unsigned k0 = blk * kBlockSlices;
         const unsigned nj = min(nslices - k0, (unsigned)kBlockSlices);
         unsigned j = 0;
-        {   // a block whose 16 slices are full in every chain of the wave, all chains packed: one statement does it
-            const bool whole = packed && !force_tail_path && (unsigned long long)(k0 + kBlockSlices) * 20u <= samples;
-            if (__builtin_amdgcn_ballot_w64(!whole) == 0ull) {
-                typedef __attribute__((address_space(3))) int *lds_int;
-                const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
+        {   // a block whose 16 slices are full in every chain of the wave: block statements
+            const bool whole = !force_tail_path && (unsigned long long)(k0 + kBlockSlices) * 20u <= samples;
+            const bool block_ok = __builtin_amdgcn_ballot_w64(!whole) == 0ull;
+            typedef __attribute__((address_space(3))) int *lds_int;
+            const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
+            // the packed forms, while every chain of the wave is packed and they are not sitting out
+            if (block_ok && pk_cooldown == 0 && __builtin_amdgcn_ballot_w64(!packed) == 0ull) {
                 if (allow_spec && spec_cooldown == 0) {
                     if (lds_tables) {
                         j = run_block_spec_ldsq(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, qtab_addr,
@@ -737,12 +770,30 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 if (j < kBlockSlices) {
                     const unsigned j0 = j;
                     j += run_block_pk(tile0 + 4u * kSliceDwords * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
-                    // (a decline found here is counted once, by the slice loop below, which evaluates slice j again)
+                    j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+                    if (j < kBlockSlices) { // a candidate left the i16 window: the 32-bit statement (or the slice loop) goes on
+                        pk_streak = min(pk_streak + 1u, 6u);
+                        if (pk_streak >= 2u && allow_b32) pk_cooldown = (kSpecCooldownBlocks << (pk_streak - 2u)) + 1;
+                        if (allow_b32 && stats && sf == 0) atomicAdd(&stats[0], 1ull); // (else the slice loop below counts it)
+                    } else {
+                        pk_streak = 0;
+                    }
                 }
+            }
+            // whatever is left of a whole block -- the packed forms declined a slice, are sitting out, or a chain's state
+            // does not fit them -- runs on the 32-bit block statement, which cannot decline
+            if (block_ok && allow_b32 && j < kBlockSlices) {
+                if (packed) pk_unpack(pk, st);
+                else if (allow_packed && stats && sf == 0) atomicAdd(&stats[1], (unsigned long long)(kBlockSlices - j));
+                if (stats && lane == 0) atomicAdd(&stats[5], (unsigned long long)(kBlockSlices - j));
+                run_block_32(tile0 + 4u * kSliceDwords * j, cand_addr, outb_addr + 8u * j, dummy_addr, sf, kc, kBlockSlices - j, st);
+                j = kBlockSlices;
+                packed = pk_try_pack(st, pk) && allow_packed;
             }
             if (spec_cooldown) spec_cooldown--;
             if (cheap_cooldown) cheap_cooldown--;
             if (pen_cooldown) pen_cooldown--;
+            if (pk_cooldown) pk_cooldown--;
         }
         for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);

@@ -53,12 +53,13 @@ def test_fuzz_ragged_batches_round_trip(gpu, oracle, seed):
             oo += gpu.encoded_size(ch, ns)
         pcm = torch.from_numpy(np.concatenate(parts)).cuda()
         outs = []
-        for fl in (0, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT):
+        for fl in (0, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT, batch.PLAN_NO_BLOCK32,
+                   batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32):
             out = torch.zeros(oo, dtype=torch.uint8, device="cuda")
             batch.EncodePlan(clips, fl).run(pcm, out)
             torch.cuda.synchronize()
             outs.append(out.cpu().numpy())
-        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
         for (p_, o_, d), x in zip(clips, parts):
             want = oracle.encode_all(x, d.channels, d.sample_rate, d.samples)
             assert outs[0][o_:o_ + len(want)].tobytes() == want, shapes

@@ -129,13 +129,15 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "nospec", "exactq", "ldsq", "ldsq_cpw1"])
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "step32_slices", "noblock32", "nospec", "exactq", "ldsq",
+                                   "ldsq_cpw1"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
     fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
           "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP,
+          "step32_slices": batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32, "noblock32": batch.PLAN_NO_BLOCK32,
           "nospec": batch.PLAN_NO_SPECULATION, "exactq": batch.PLAN_EXACT_QUOTIENT,
           "ldsq": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_4,
           "ldsq_cpw1": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_1}[flags]
@@ -534,7 +536,7 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     pcm = torch.from_numpy(fixture_pcm).cuda()
     outs = []
     for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT,
-                  batch.PLAN_NO_PENALTY_FORM):
+                  batch.PLAN_NO_PENALTY_FORM, batch.PLAN_NO_BLOCK32, batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32):
         plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
@@ -559,9 +561,11 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
             assert misses == 0 and declined + unpacked <= 2 * ((n + 19) // 20) // 200
         elif flags == batch.PLAN_NO_PENALTY_FORM:
             assert plan.counters()[7] == 0 and 0 < misses <= 2 * ((n + 19) // 20) // 20
+        elif flags == batch.PLAN_NO_BLOCK32:
+            assert declined + unpacked <= 2 * ((n + 19) // 20) // 200
         else:
             assert (declined, unpacked, misses) == (0, 0, 0)
-    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4] == oracle.encode_all(fixture_pcm, 2, 44100, n)
+    assert all(o == outs[0] for o in outs[1:]) and outs[0] == oracle.encode_all(fixture_pcm, 2, 44100, n)
 
 
 @pytest.mark.parametrize("gain", [1.5, 3.0, 8.0])
@@ -576,7 +580,7 @@ def test_cheap_quotient_on_loud_material(gpu, oracle, fixture_pcm, gain):
     clips = [(0, 0, gpu.QoaDesc(2, 44100, n))]
     pcm = torch.from_numpy(x).cuda()
     outs, declines, marks = [], [], []
-    for flags in (batch.PLAN_DEFAULT, batch.PLAN_EXACT_QUOTIENT, batch.PLAN_CPW_1):
+    for flags in (batch.PLAN_DEFAULT, batch.PLAN_EXACT_QUOTIENT, batch.PLAN_CPW_1, batch.PLAN_NO_BLOCK32):
         plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
@@ -584,7 +588,7 @@ def test_cheap_quotient_on_loud_material(gpu, oracle, fixture_pcm, gain):
         declines.append(c[3])
         marks.append(c[4])
         outs.append(out.cpu().numpy().tobytes())
-    assert outs[0] == outs[1] == outs[2] == oracle.encode_all(x, 2, 44100, n)
+    assert outs[0] == outs[1] == outs[2] == outs[3] == oracle.encode_all(x, 2, 44100, n)
     print(f"gain {gain}: a candidate marked in {marks[0]} slices, {declines[0]} of them declined, of {2 * n // 20} slices")
     assert declines[1] == 0 and marks[1] == 0
     assert marks[0] > 0 and marks[2] > 0        # the marking path runs ...

@@ -27,13 +27,21 @@ SPK0 = SMP0 + 10
 RANK_EXACT_BELOW = 32767 * 32767   # saturating 32-bit rank of the speculative forms: below this value it is the true rank
 
 
-def step(i):
+STEP_OPERANDS = dict(h=[f"%[h{j}]" for j in range(4)], w=[f"%[w{j}]" for j in range(4)], acca="%[acca]", accb="%[accb]",
+                     e="%[e]", pen="%[pen]", aerr0="%[aerr0]")
+# the 32-bit block loop (b32_block) keeps the state in fixed registers: v[84:87] history, v[88:91] weights = the two halves of
+# a candidate's 32-byte LDS slot
+B32_FIXED = dict(h=[f"v{84 + j}" for j in range(4)], w=[f"v{88 + j}" for j in range(4)], acca="v77", accb="v78",
+                 e="v[82:83]", pen="v76", aerr0="v79")
+
+
+def step(i, N=STEP_OPERANDS):
     b = i % 4
-    h = [f"%[h{(b + j) % 4}]" for j in range(4)]          # oldest .. newest
+    h = [N["h"][(b + j) % 4] for j in range(4)]            # oldest .. newest
     s = [f"v{S0 + (b + j) % 4}" for j in range(4)]
-    w = [f"%[w{j}]" for j in range(4)]
+    w = N["w"]
     smp = f"v{SMP0 + i}"
-    acc = "%[acca]" if i < 10 else "%[accb]"
+    acc = N["acca"] if i < 10 else N["accb"]
     p, q = f"v[{P}:{P + 1}]", f"v[{Q}:{Q + 1}]"
     L = [
         f"v_mul_lo_u32 v{P}, {w[0]}, {h[0]}",
@@ -52,7 +60,7 @@ def step(i):
         f"v_add_u32 v{Q}, 0xfffff701, v{Q}",
         f"v_med3_i32 v{T}, v{T}, -1, 1",
         f"v_ashrrev_i32 v{U}, 16, v{U}",
-        f"v_mad_i32_i24 %[pen], v{Q}, v{Q}, %[pen]",
+        f"v_mad_i32_i24 {N['pen']}, v{Q}, v{Q}, {N['pen']}",
         f"v_lshl_add_u32 v{SNEG}, v{T}, 1, v{U}",           # n + 2 sgn(residual)
         f"v_med3_i32 v{U}, v{U}, v{SNEG}, v{T}",            # scaled = n + sgn(residual) - sgn(n), see cand_step()
         f"v_sub_u32 v{T}, 0, v{U}",
@@ -77,13 +85,84 @@ def step(i):
         f"v_mad_i32_i24 {w[1]}, {s[1]}, v{D}, {w[1]}",
         f"v_ashrrev_i32 {s[0]}, 31, {h[0]}",                # sign of the new sample -> the oldest sign slot
         f"v_mad_i32_i24 {w[2]}, {s[2]}, v{D}, {w[2]}",
-        f"v_mad_i64_i32 %[e], vcc, v{T}, v{T}, %[e]",
+        f"v_mad_i64_i32 {N['e']}, vcc, v{T}, v{T}, {N['e']}",
         f"v_mad_i32_i24 {w[3]}, {s[3]}, v{D}, {w[3]}",
         f"v_or_b32 {s[0]}, 1, {s[0]}",
     ]
     assert len(L) == 41
     if i == 0:  # |err| of the first sample orders the first-sample ranks
-        L += [f"v_sub_u32 v{U}, 0, v{T}", f"v_max_i32 %[aerr0], v{T}, v{U}"]
+        L += [f"v_sub_u32 v{U}, 0, v{T}", f"v_max_i32 {N['aerr0']}, v{T}, v{U}"]
+    return L
+
+
+def b32_block():
+    """Up to %[n] consecutive full slices on the 32-bit step (step(): 41 instructions, full i32 weights -- it cannot decline)
+    in one statement: the block loop's last resort for chains whose state, or whose LOSING candidates, leave the i16 window
+    slice after slice (clipped material).  Before round 3 such slices went one by one through run_slice_asm + ten
+    ds_bpermute + a re-admission test, after a wasted packed attempt: 2,100 issue slots per slice against ~900 here.
+    State: v[84:87] history, v[88:91] weights; every candidate parks both halves in its 32-byte LDS slot, the election is the
+    full form's (keys rank >> 5, then rank[6:0] : |err0| : sf << 5), all 16 lanes read the winner's slot back."""
+    N = B32_FIXED
+    K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v72", "v120"   # K1/M/K2 share the dot-product registers (dead by then)
+    TCUR, OCUR = "v74", "v75"
+    SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
+    reads = sample_reads(TCUR)
+    dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
+    L = [
+        f"v_mov_b32 {TCUR}, %[tile]",
+        f"v_subrev_u32 {OCUR}, 8, %[outb]",
+    ] + sample_reads("%[tile]") + [
+        "s_mov_b32 %[done], 0",
+        "Lqoa_top_%=:",
+        "s_waitcnt lgkmcnt(0)",                              # the slice's samples, the winner's state (a slice-word store may trail: harmless)
+    ]
+    for j in range(4):
+        L += [f"v_ashrrev_i32 v{S0 + j}, 31, {N['h'][j]}", f"v_or_b32 v{S0 + j}, 1, v{S0 + j}"]
+    L += [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0", f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"]
+    L += unpack_samples()
+    for i in range(20):
+        L += step(i, N)
+    L += [
+        f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
+        "ds_write_b128 %[cand], v[84:87]",
+        "ds_write_b128 %[cand], v[88:91] offset:16",
+        f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
+        f"v_lshlrev_b32 {K2}, 25, {ELO}",
+        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
+        f"v_or_b32 {K2}, %[sf4], {K2}",
+        f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
+        f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
+        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
+        dpp(M, 4),
+        f"v_or_b32 {SHI}, %[sfsh], {SHI}",
+        f"v_add_u32 {TCUR}, 48, {TCUR}",
+        dpp(M, 2),
+        reads[0],
+        reads[1],
+        dpp(M, 1),
+        f"v_cmp_eq_u32 vcc, {K1}, {M}",
+        f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
+        reads[2],
+        f"v_add_u32 {OCUR}, 8, {OCUR}",
+        dpp(K2, 8),
+        "s_add_u32 %[done], %[done], 1",
+        "s_cmp_lt_u32 %[done], %[n]",
+        dpp(K2, 4),
+        "s_nop 0",
+        "s_nop 0",
+        dpp(K2, 2),
+        "s_nop 0",
+        "s_nop 0",
+        dpp(K2, 1),
+        f"v_bfi_b32 {ADDR}, %[mf0], {K2}, %[cand]",          # the winner's slot
+        f"ds_read_b128 v[84:87], {ADDR}",
+        f"ds_read_b128 v[88:91], {ADDR} offset:16",
+        f"v_cmp_eq_u32 vcc, {ADDR}, %[cand]",
+        f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
+        f"ds_write_b64 {OADDR}, v[80:81]",
+        "s_cbranch_scc1 Lqoa_top_%=",
+        "s_waitcnt lgkmcnt(0)",
+    ]
     return L
 
 
@@ -706,6 +785,7 @@ def render(verbose=False):
     blk_ldsq = pk_block(verbose, spec=True, ldsq=True)
     blk_cheap = pk_block(verbose, spec=True, cheap=True)
     blk_pen = pk_block(verbose, spec=True, cheap=True, pen=True)
+    blk_32 = b32_block()
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
            "// QOA_SLICE_PK_ASM_TEXT: 20 x 35-instruction steps on i16-packed weights and history (fast path).\n"
@@ -723,8 +803,11 @@ def render(verbose=False):
            + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap) + "\n"
            + "// QOA_BLOCK_PEN_ASM_TEXT: the cheap-quotient loop WITH the penalty arithmetic on every step (27/step): what the\n"
            + "//   block loop falls back to where the speculative forms miss (winners that carry a penalty), before the full form.\n"
-           + emit("QOA_BLOCK_PEN_ASM_TEXT", blk_pen))
-    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap), len(blk_pen))
+           + emit("QOA_BLOCK_PEN_ASM_TEXT", blk_pen) + "\n"
+           + "// QOA_BLOCK_32_ASM_TEXT: a loop over consecutive full slices on the 32-bit step (it cannot decline): the block loop's\n"
+           + "//   last resort; state in v[84:91], fixed registers v72-v127.\n"
+           + emit("QOA_BLOCK_32_ASM_TEXT", blk_32))
+    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap), len(blk_pen), len(blk_32))
 
 
 INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")
