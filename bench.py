@@ -162,7 +162,7 @@ def signal_classes(q, batch, synth, dev, stream, ch, rate, n_clips=256, frames=6
         res[kind] = {"kernel_ms": float(np.mean(ms)), "samples_per_s": plan.samples / (float(np.mean(ms)) * 1e-3),
                      "bit_exact_vs_oracle": bool(ok),
                      "counters": {"declined_slices": c[0], "unpacked_slices": c[1], "speculation_misses": c[2],
-                                  "cheap_quotient_declines": c[3], "cheap_quotient_marked_wave_slices": c[4],
+                                  "cheap_quotient_declines": c[3], "cheap_quotient_marked_candidates": c[4],
                                   "slices_total": n_clips * ch * frames * 256}}
         del plan, cplan, pcm
     if "music" in res:
@@ -410,7 +410,7 @@ def main():
         cplan.run(pcm, out, stream)
         declined, unpacked, misses, cheap_declined, marked = cplan.counters()[:5]
         result["packed_path"] = {"declined_slices": declined, "unpacked_slices": unpacked, "speculation_misses": misses,
-                                 "cheap_quotient_declines": cheap_declined, "cheap_quotient_marked_wave_slices": marked,
+                                 "cheap_quotient_declines": cheap_declined, "cheap_quotient_marked_candidates": marked,
                                  "slices_total": n_clips * ch * ((samples + 19) // 20), "launches": 1}
         del cplan
         if world > 1 and gathered is not None:

@@ -174,7 +174,8 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
  *   out[3] slices the cheap-quotient step form declined (level from |quotient|, sign from the residual: exact unless a
  *          scalefactor-0/1 candidate's quotient wraps to the opposite sign; such a candidate is marked and must be beaten by
  *          a bound derived from the slice's samples, else the slice is repeated with the exact qoa_div -- loud passages);
- *   out[4] (wavefront, slice) pairs in which a candidate was marked at all (most are settled in place by the bound);
+ *   out[4] (candidate, slice) pairs marked at all (most are settled in place: the marked candidate enters the election
+ *          with the rank it provably costs at least, and loses);
  *   out[5] (wavefront, slice) pairs evaluated on the 32-bit step (block statement, one-slice statement or tail path), out[6] on the one-slice packed statement;
  *   out[7] slices the penalty form (cheap-quotient steps with the penalty arithmetic: the fall-back for speculation
  *          misses) declined and handed to the full form.

@@ -94,7 +94,7 @@ class EncodePlan:
         return a.value, b.value, c.value
 
     def counters(self) -> Tuple[int, ...]:
-        """stats() + (slices the cheap-quotient step form declined, wavefront-slices in which it marked a candidate,
+        """stats() + (slices the cheap-quotient step form declined, (candidate, slice) pairs it marked,
         wavefront-slices on the 32-bit / tail path, wavefront-slices on the one-slice packed statement, slices the
         penalty form declined)
         (qoa_encode_plan_counters)."""

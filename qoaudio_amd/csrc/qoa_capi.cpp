@@ -136,7 +136,11 @@ struct EncGroup {
     DevBuf lms;
 };
 
+#ifdef QOA_LAB_STAMPS
+constexpr size_t kCounters = 12; // + the timing experiment's four (tools/k1lab/stamps.sh)
+#else
 constexpr size_t kCounters = 8; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
+#endif
 struct qoa_encode_plan {
     std::vector<EncGroup *> groups;
     uint64_t pcm_bytes = 0, out_bytes = 0, samples = 0;

@@ -31,7 +31,10 @@
 
 #include "qoa_format.h"
 #include "qoa_kernels.h"
-#include "qoa_slice_asm.inc"
+#ifndef QOA_SLICE_ASM_INC // (tools/k1lab builds timing variants of the generated texts)
+#define QOA_SLICE_ASM_INC "qoa_slice_asm.inc"
+#endif
+#include QOA_SLICE_ASM_INC
 
 #include "qoa_device.h"
 
@@ -305,16 +308,16 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
 template <bool CHEAP>
 __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
                                                    int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk,
-                                                   unsigned *marked_slices = nullptr) {
+                                                   unsigned *marked_pairs = nullptr, unsigned long long *lab = nullptr) {
     register unsigned w01 asm("v84") = pk.w01;
     register unsigned w23 asm("v85") = pk.w23;
     register unsigned pa asm("v86") = pk.pa;
     register unsigned pb asm("v87") = pk.pb;
-    unsigned done, marks;
+    unsigned done, tmp;
 #define QOA_SPEC_CLOBBERS                                                                                                  \
     "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",  \
         "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",  \
-        "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",    \
+        "v97", "v98", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",          \
         "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", \
         "v127"
 #define QOA_SPEC_INPUTS                                                                                                    \
@@ -323,16 +326,26 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
         [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),       \
         [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
     if constexpr (CHEAP) {
+        register unsigned marks asm("v99"); // this lane's marked (candidate, slice) pairs of the call
+#ifdef QOA_LAB_STAMPS // timing experiment (tools/k1lab/stamps.py): cycles inside the 20 steps / in the rest of the slice loop
+        unsigned tb, tt;
         asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
-                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [marks] "=&s"(marks)
+                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks), [tb] "=&s"(tb), [tt] "=&s"(tt)
+                     : QOA_SPEC_INPUTS
+                     : QOA_SPEC_CLOBBERS, "s86", "s87", "s88", "s89", "s90", "s91", "s92");
+        if (lab) { lab[0] += tb; lab[1] += tt; }
+#else
+        asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
+                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks)
                      : QOA_SPEC_INPUTS
                      : QOA_SPEC_CLOBBERS);
-        if (marked_slices) *marked_slices = marks;
+#endif
+        if (marked_pairs) *marked_pairs = marks;
     } else {
         asm volatile(QOA_BLOCK_SPEC_ASM_TEXT
-                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
+                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
                      : QOA_SPEC_INPUTS
-                     : QOA_SPEC_CLOBBERS);
+                     : QOA_SPEC_CLOBBERS, "v99");
     }
 #undef QOA_SPEC_INPUTS
 #undef QOA_SPEC_CLOBBERS
@@ -352,16 +365,17 @@ __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned c
     register unsigned w23 asm("v85") = pk.w23;
     register unsigned pa asm("v86") = pk.pa;
     register unsigned pb asm("v87") = pk.pb;
-    unsigned done, marks;
+    unsigned done, tmp;
+    register unsigned marks asm("v99");
     asm volatile(QOA_BLOCK_PEN_ASM_TEXT
-                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [marks] "=&s"(marks)
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks)
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
                    [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
-                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),
-                   [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp), [limit] "s"(kPkPenLimit)
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [limitv] "v"(kPkPenLimit), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
+                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
                  : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
                    "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
-                   "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                   "v95", "v96", "v97", "v98", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
                    "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
                    "v124", "v125", "v126", "v127");
     (void)marks;
@@ -410,9 +424,9 @@ __device__ __forceinline__ unsigned run_block_spec_ldsq(unsigned tile_addr, unsi
     register unsigned w23 asm("v85") = pk.w23;
     register unsigned pa asm("v86") = pk.pa;
     register unsigned pb asm("v87") = pk.pb;
-    unsigned done;
+    unsigned done, tmp;
     asm volatile(QOA_BLOCK_SPEC_LDSQ_ASM_TEXT
-                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done)
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
                    [sf4] "v"((unsigned)sf << 5), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [qtab] "v"(qtab),
                    [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq),
@@ -542,7 +556,8 @@ __device__ __forceinline__ void load_block_lane(const int16_t *__restrict__ p, u
 
 // What a candidate of the slice costs at least if its quotient wraps to the opposite sign (cheap-quotient form, see
 // run_block_spec): at that step |residual| >= 32768 and |dequantised| <= 49, so |error| >= min(32719, 32767 - max|sample|).
-// Returns the square; the block loop demands that the winner's rank stays below it whenever a candidate was marked.
+// Returns the square less one (at least 0): the rank a marked candidate takes into the election, so that it wins -- and the
+// slice is abandoned -- exactly when the best unmarked rank is not below the bound (pk_block_spec in the generator).
 __device__ __forceinline__ unsigned marked_bound(const unsigned (&pairs)[10]) {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     s16x2 mx = __builtin_bit_cast(s16x2, pairs[0]), mn = mx;
@@ -555,7 +570,7 @@ __device__ __forceinline__ unsigned marked_bound(const unsigned (&pairs)[10]) {
     const int hi = max((int)mx.x, (int)mx.y), lo = min((int)mn.x, (int)mn.y);
     const int smax = max(hi, -lo);
     const int lb = max(min(32719, 32767 - smax), 0);
-    return (unsigned)(lb * lb);
+    return (unsigned)max(lb * lb, 1) - 1u; // the rank a marked candidate takes into the election: its bound, less one (pk_block_spec)
 }
 
 // the slice at `src` (tile layout: bound, unused, 10 pairs) widened to 20 ints
@@ -647,6 +662,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // seconds; full-scale noise and clipped material never leave it), an isolated miss costs the rest of its block only.
     unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0, pk_cooldown = 0, pk_streak = 0;
 
+#ifdef QOA_LAB_STAMPS // stats[8..11]: wave cycles in the steps / rest of the slice loop / the whole statement / the kernel
+    unsigned long long lab_acc[3] = {0, 0, 0};
+    const unsigned long long lab_k0 = __builtin_readcyclecounter();
+#endif
     Lms st;
     if (flags & 2u) { // fresh encoder: history 0, weights [0, 0, -(1<<13), 1<<14] (src/lib.rs:346-352)
         st.h0 = st.h1 = st.h2 = st.h3 = 0;
@@ -728,10 +747,17 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                             const bool cheap = allow_cheap && cheap_cooldown == 0;
                             if (cheap) {
                                 unsigned marked;
+#ifdef QOA_LAB_STAMPS
+                                const unsigned long long lab_c0 = __builtin_readcyclecounter();
+                                j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
+                                                          dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked, lab_acc);
+                                lab_acc[2] += __builtin_readcyclecounter() - lab_c0;
+#else
                                 j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
                                                           dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
+#endif
                                 j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-                                if (stats && marked && lane == 0) atomicAdd(&stats[4], (unsigned long long)marked);
+                                if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
                                 if (j == kBlockSlices) break;
                                 if (stats && sf == 0) atomicAdd(&stats[3], 1ull);
                                 if (blk - last_cheap_decline <= 1u) cheap_cooldown = kCheapCooldownBlocks + 1;
@@ -866,6 +892,12 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         s[0] = st.h0; s[1] = st.h1; s[2] = st.h2; s[3] = st.h3;
         s[4] = st.w0; s[5] = st.w1; s[6] = st.w2; s[7] = st.w3;
     }
+#ifdef QOA_LAB_STAMPS
+    if (stats && lane == 0) {
+        atomicAdd(&stats[8], lab_acc[0]); atomicAdd(&stats[9], lab_acc[1]); atomicAdd(&stats[10], lab_acc[2]);
+        atomicAdd(&stats[11], __builtin_readcyclecounter() - lab_k0);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

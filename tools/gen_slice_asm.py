@@ -205,7 +205,9 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     if N.get("alt") and i % 2:  # second temporary set: lets the scheduler overlap neighbouring steps
         P, Q, PR, T, U, SN, D, X, E = N["alt"]
     sub_t = f"v_sub_u32 {T}, {smp}, {PR}"                  # residual
-    if i == 0:
+    if i == 0 and N.get("acc_cleared"):                    # (the block loop clears the slice-word halves in its election's gaps)
+        slot_a, slot_b = None, None
+    elif i == 0:
         slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0" + N.get("fill", ""), f"v_mov_b32 {N['accb']}, 0" + N.get("fill", "")
     elif spec:
         if N.get("alt") and i % 4 == 0:
@@ -304,7 +306,8 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
-        assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0)
+        assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0) - (
+            2 if i == 0 and N.get("acc_cleared") else 0)
         if i == 2:
             k = L.index(slot_b) + 1
             L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
@@ -584,6 +587,9 @@ def schedule(lines):
     return order, back_to_back
 
 
+LAB = set(filter(None, os.environ.get("QOA_GEN_LAB", "").split(",")))   # timing experiments (tools/k1lab/stamps.sh); never in the product
+
+
 def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
@@ -613,6 +619,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
     falls back to where the speculative forms miss -- tonal passages, whose winners carry a penalty (3 % of real music's
     slices, clustered) -- instead of the 35-instruction full form."""
     assert not pen or (spec and cheap and not ldsq)
+    stamps = "stamps" in LAB and cheap and not pen       # s90 = cycles in the 20 steps, s91 = cycles in the rest of the loop
     N = dict(PK_FIXED, **SPEC_REGS) if spec else PK_FIXED
     assert not spec or (N["R"][3], N["RC"][1], PK_S[2], PK_S[3]) == ("v92", "v93", "v94", "v95")   # = SLOT2
     K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v76", "v120"   # K1/M/K2 share the dot registers (long dead by now)
@@ -623,83 +630,42 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
     reads = sample_reads(TCUR)
     if spec:
         K1 = ELO
-    prev = PADDR if spec else ADDR
     dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
-    # full form: rank and penalty sums are cleared for the next slice; the speculative rank starts from an inline 0
-    zero = [] if spec else [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0"]
     assert ELO == ELO_REG
-    L = []
-    L += [
+    if spec:
+        return pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, dict(
+            K1=K1, M=M, K2=K2, ADDR=ADDR, OADDR=OADDR, TCUR=TCUR, OCUR=OCUR, SHI=SHI, SLO=SLO, ELO=ELO, CANDC=CANDC,
+            PADDR=PADDR, THR=THR, QM=QM, reads=reads, dpp=dpp))
+    # ---- the full form ----
+    zero = [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0"]   # rank and penalty sums are cleared for the next slice
+    L = [
         "s_mov_b32 s95, 0x10001",
-    ] + ([f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW:x}"] if spec else []) + ([f"v_mov_b32 {CH_BIG}, 0x7fffffff", "s_mov_b32 %[marks], 0"] if cheap else []) + [
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an early exit restores
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
-        f"v_mov_b32 {prev}, %[cand]",
-    ] + ([f"v_mov_b32 {CANDC}, %[cand]"] if spec else []) + sample_reads("%[tile]") + zero + (
-        pk_prologue(N, zero=False, spec=True) if spec else []) + [   # speculative loops: once per call; then SLOT2 carries it
+        f"v_mov_b32 {ADDR}, %[cand]",
+    ] + sample_reads("%[tile]") + zero + [
         "s_mov_b32 %[done], 0",
         "s_waitcnt lgkmcnt(0)",
         "Lqoa_top_%=:",
-        # the winner's state; a slice-word store may trail, and in the speculative loops SLOT2's read (waited for below)
-        f"s_waitcnt lgkmcnt({2 if spec else 1})",
-    ] + ([f"v_mov_b32 {N['pen']}, 0"] if pen else [])
-    body = [] if spec else pk_prologue(N, zero=False)        # rank and penalty sums are cleared in the election's gaps
-    if ldsq:
-        N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
-    elif spec:
-        N = dict(N, fill=FILL, cheap=cheap, pen_steps=pen)
-    acc_line = None
+        "s_waitcnt lgkmcnt(1)",                              # the winner's state; a slice-word store may trail
+    ]
+    body = pk_prologue(N, zero=False)                        # rank and penalty sums are cleared in the election's gaps
     for i in range(20):
-        if ldsq:
-            lines, acc_line = pk_step_ldsq(i, N, acc_line)
-            body += lines
-        else:
-            body += pk_step(i, N, spec)
-    if ldsq:
-        body.append(acc_line)
-    if not spec:
-        E = N["alt"][8]                                      # step 19 used the second temporary set
-        body = unpack_samples() + body + [
-            f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
-            f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
-            f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
-        ]
-    elif not ldsq:
-        E = N["alt"][8]                                      # pair 9: the odd pairs' register (pk_step)
-        body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,       # the last error pair (spec_rank_pair)
-                 f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL,
-                 # the first test below, as one more filler
-                 (f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]" if pen else f"v_cmp_ge_i32 vcc, {QM}, %[limq]") + FILL]
-        if pen:   # total rank = err^2 sum + penalty sum (both < 2^31: no carry); scheduled, so the v_dot2 wait states hold
-            body.append(f"v_add_u32 {ELO}, {ELO}, {N['pen']}")
-        if cheap:
-            body.append(f"v_mov_b32 {CH_BND}, s94" + FILL)   # the winner's rank limit when no candidate is marked
-    if ldsq:
-        b2b = -1                                             # kept in program order (see pk_step_ldsq)
-    else:
-        body, b2b = schedule(body)
+        body += pk_step(i, N, False)
+    E = N["alt"][8]                                          # step 19 used the second temporary set
+    body = unpack_samples() + body + [
+        f"v_sub_u32 {E}, v{SMP0 + 19}, {PK_RC[1]}",
+        f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}",
+        f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
+    ]
+    body, b2b = schedule(body)
     if verbose:
-        print(f"block body{' (speculative)' if spec else ''}: {len(body)} instructions after scheduling, "
-              f"{b2b} consumers directly behind their producer")
-    if spec:   # SLOT2 is first needed near the end of step 0: wait for it there, not at the loop top
-        first = min(k for k, l in enumerate(body) if l.startswith("v_") and set(_parse(l)[2]) & {"v92", "v93", "v94", "v95"})
-        body.insert(first, "s_waitcnt lgkmcnt(1)")
-    tail = []
-    if cheap and body[-2] == "s_nop 0" and body[-1].startswith("v_dot2") and body[-3].startswith("v_pk_sub"):
-        # the first exit branch serves as the wait state between the last error pair's v_pk_sub and its v_dot2 (a declined
-        # slice does not need the rank); the v_dot2 still has v_cmp, branch, v_xor, v_lshl_or in front of the first DPP read
-        tail = [body[-1]]
-        body = body[:-2]
+        print(f"block body: {len(body)} instructions after scheduling, {b2b} consumers directly behind their producer")
     L += body
-    L += ([] if spec and not ldsq else
-          [f"v_cmp_ge_i32 vcc, {QM}, %[limq]" if spec else f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]"]) + [
+    L += [
+        f"v_cmp_ge_u32 vcc, {N['pen']}, %[limit]",
         "s_cbranch_vccnz Lqoa_declined_%=",
-    ] + tail + ([
-        f"v_cmp_gt_i32 vcc, 0, {CH_W}",                      # any candidate marked (cheap_quotient_note)?
-        "s_cbranch_vccnz Lqoa_marked_%=",
-        "Lqoa_unmarked_%=:",
-    ] if cheap else []) + ([f"v_xor_b32 {CANDC}, %[pp], {CANDC}"] if spec else []) + ([   # the other slot buffer: the entry state stays put
         # keys of the full form: rank < 2^37 -> rank >> 5, then rank[7:0] : |err0| : sf << 4
         # (slots are 32 bytes apart: %[sf4] = sf << 5, %[mf0] = 0x1e0; the second key keeps rank[6:0] : |err0| : sf << 5)
         f"ds_write_b128 {cand}, v[84:87]",
@@ -707,10 +673,6 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
         f"v_lshlrev_b32 {K2}, 25, {ELO}",
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
         f"v_or_b32 {K2}, %[sf4], {K2}",
-    ] if not spec else [
-        # speculative form: the saturating rank is one dword; second key |err0| : sf << 5
-        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]",
-    ]) + [
         f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
         f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
@@ -726,44 +688,170 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
         reads[2],
         f"v_add_u32 {OCUR}, 8, {OCUR}",
         dpp(K2, 8),
-        f"ds_write_b128 {cand}, v[84:87]" if spec else "s_nop 0",
-        f"ds_write_b128 {cand}, {SLOT2} offset:16" if spec else "s_nop 0",
+        "s_nop 0",
+        "s_nop 0",
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
         "s_cmp_lt_u32 %[done], %[n]",
         dpp(K2, 2),
-    ] + (zero if not spec else [                             # full form: clear e and pen for the next slice (dead by now)
-        f"v_cmp_le_u32 vcc, {CH_BND if cheap else 's94'}, {M}",   # speculative form: is the winner's rank its true rank?
-        "s_cbranch_vccnz Lqoa_late_%=",                      # (see spec_rank_pair; the slice then goes to the full form)
-    ]) + [
+    ] + zero + [                                             # clear e and pen for the next slice (dead by now)
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {cand}",           # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
-    ] + ([f"ds_read_b128 {SLOT2}, {ADDR} offset:16"] if spec else []) + ["s_nop 0"] * int(os.environ.get("QOA_GEN_NOPS_BEHIND_STATE_READ", "0")) + [   # (experiment: how long is the read exposed?)
         f"v_cmp_eq_u32 vcc, {ADDR}, {cand}",
         f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
-    ] + ([f"v_cndmask_b32 {THR}, %[limq], %[winq], vcc"] if spec and not pen else []) + [   # non-winners: the test they already passed
         f"ds_write_b64 {OADDR}, v[80:81]",
-    ] + ([
-        f"v_cmp_ge_i32 vcc, {QM}, {THR}",                    # can only fire in the winner's lane
-        "s_cbranch_vccnz Lqoa_late_%=",
-    ] if spec and not pen else []) + ([
-        f"v_mov_b32 {PADDR}, {ADDR}",                        # this slice is final: its winner's slot holds the next entry state
-    ] if spec else []) + [
         "s_cbranch_scc1 Lqoa_top_%=",
         "s_branch Lqoa_end_%=",
-    ] + ([
-        "Lqoa_marked_%=:",
-        "s_add_u32 %[marks], %[marks], 1",                   # (diagnostics: slices of this call with a marked candidate)
-        f"v_cndmask_b32 {ELO}, {ELO}, {CH_BIG}, vcc",        # marked candidates leave the election ...
-        f"v_mov_b32 {CH_BND}, {BOUND_IN}",                   # ... and the winner must beat what they provably cost
-        "s_branch Lqoa_unmarked_%=",
-    ] if cheap else []) + (["Lqoa_late_%=:", "s_sub_u32 %[done], %[done], 1"] if spec else []) + [
         "Lqoa_declined_%=:",
-        f"ds_read_b128 v[84:87], {prev}",                    # entry state of the declined slice
+        f"ds_read_b128 v[84:87], {ADDR}",                    # entry state of the declined slice
         "Lqoa_end_%=:",
         "s_waitcnt lgkmcnt(0)",
     ]
+    return L
+
+
+def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
+    """The speculative block loops (exact quotient, cheap quotient, LDS tables, penalty form).  ONE branch per slice:
+    a not-taken s_cbranch_vccnz behind its v_cmp costs a lone wavefront ~24 cycles and a taken branch ~21
+    (tools/ubench/branchbench.hip) -- the four exit tests of round 2's loop plus the loop branch were 4.6 % of the slice.
+    Every exit condition is therefore folded into one per-lane comparison at the end of the slice (the candidate slots
+    are double-buffered, so any slice can still be abandoned there: its entry state is in the other buffer):
+
+      QMv >= THR   with  THR = winner lane ? WQ : LQ
+        QMv  the candidate's running energy maximum (penalty form: its penalty sum)
+        LQ   %[limq] (penalty form: %[limit]): some candidate's i16 arithmetic may have wrapped -- any lane;
+             replaced by "always" when the row's best rank M is not provably exact (M >= 32767^2, spec_rank_pair)
+        WQ   %[winq]: the winner's penalty was not provably zero (not in the penalty form);
+             replaced by "always" in a MARKED lane (cheap quotient, cheap_quotient_note): a marked candidate stays in the
+             election with rank BKEY = max(bound, 1) - 1, bound being what it provably costs at least (tile dword 0), so it
+             wins exactly when the best unmarked rank is not below the bound -- or ties with BKEY, which declines too.
+    "always" is INT_MIN for the signed energy comparison and 0 for the unsigned penalty comparison (CH_BIG).
+    The loop branch is taken when no lane's comparison fired and slices are left: tmp = fired ? -1 : done; tmp < n."""
+    K1, M, K2, ADDR, OADDR, TCUR, OCUR = G["K1"], G["M"], G["K2"], G["ADDR"], G["OADDR"], G["TCUR"], G["OCUR"]
+    SHI, SLO, ELO, CANDC, PADDR, THR, QM, reads, dpp = (G[k] for k in ("SHI", "SLO", "ELO", "CANDC", "PADDR", "THR", "QM",
+                                                                       "reads", "dpp"))
+    WQ, MK = "v83", CH_BND                                   # v83: the rank's high dword in the full form, unused here
+    if cheap:
+        K1 = "v116"                                          # the election's copy of the rank (a v_dot2's result may not be overwritten so soon)
+    LQ = QM if pen else N["pen"]                             # a register the form does not use otherwise
+    QMV = N["pen"] if pen else QM
+    LIMV = "%[limitv]"                                       # penalty form: kPkPenLimit in a VGPR (v_cndmask reads vcc: no SGPR source besides)
+    cmp_ge = "v_cmp_ge_u32" if pen else "v_cmp_ge_i32"
+    L = [
+        "s_mov_b32 s95, 0x10001",
+        f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW:x}",
+        f"v_mov_b32 {CH_BIG}, {'0' if pen else '0x80000000'}",
+    ] + ([f"v_mov_b32 {MK}, 0"] if cheap else []) + [
+        "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an exit restores
+        f"v_mov_b32 {TCUR}, %[tile]",
+        f"v_subrev_u32 {OCUR}, 8, %[outb]",
+        f"v_mov_b32 {ADDR}, %[cand]",
+        f"v_mov_b32 {CANDC}, %[cand]",
+    ] + sample_reads("%[tile]") + pk_prologue(N, zero=False, spec=True) + (   # once per call; then SLOT2 carries it
+        [] if ldsq else [f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"]) + [
+        "s_mov_b32 %[done], 0",
+    ] + (["s_mov_b32 s90, 0", "s_mov_b32 s91, 0", "s_memtime s[88:89]"] if stamps else []) + [
+        "s_waitcnt lgkmcnt(0)",
+        "Lqoa_top_%=:",
+        f"v_mov_b32 {PADDR}, {ADDR}",                        # the slot that holds this slice's entry state
+        # the winner's state; a slice-word store may trail, and SLOT2's read (waited for below)
+        "s_waitcnt lgkmcnt(2)",
+    ] + (["s_memtime s[86:87]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s86, s88", "s_add_u32 s91, s91, s92"] if stamps else []) + (
+        [f"v_mov_b32 {N['pen']}, 0"] if pen else [])
+    body = []
+    if ldsq:
+        N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
+    else:
+        N = dict(N, fill=FILL, cheap=cheap, pen_steps=pen, acc_cleared=True)
+    acc_line = None
+    for i in range(20):
+        if ldsq:
+            lines, acc_line = pk_step_ldsq(i, N, acc_line)
+            body += lines
+        else:
+            body += pk_step(i, N, True)
+    if ldsq:
+        body.append(acc_line)
+        b2b = -1                                             # kept in program order (see pk_step_ldsq)
+    else:
+        E = N["alt"][8]                                      # pair 9: the odd pairs' register (pk_step)
+        body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,       # the last error pair (spec_rank_pair)
+                 f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL,
+                 f"v_xor_b32 {CANDC}, %[pp], {CANDC}" + FILL]                      # the other slot buffer: the entry state stays put
+        if cheap:
+            body.append(f"v_cmp_gt_i32 vcc, 0, {CH_W}" + FILL)                     # marked lanes (cheap_quotient_note)
+        if pen:   # total rank = err^2 sum + penalty sum (both < 2^31: no carry); scheduled, so the v_dot2 wait states hold
+            body.append(f"v_add_u32 {ELO}, {ELO}, {N['pen']}")
+        body, b2b = schedule(body)
+    if verbose:
+        print(f"block body (speculative{', cheap' if cheap else ''}{', penalty' if pen else ''}{', lds' if ldsq else ''}): "
+              f"{len(body)} instructions after scheduling, {b2b} consumers directly behind their producer")
+    # SLOT2 is first needed near the end of step 0: wait for it there, not at the loop top
+    first = min(k for k, l in enumerate(body) if l.startswith("v_") and set(_parse(l)[2]) & {"v92", "v93", "v94", "v95"})
+    body.insert(first, "s_waitcnt lgkmcnt(1)")
+    L += body
+    if stamps:
+        L += ["s_memtime s[88:89]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s88, s86", "s_add_u32 s90, s90, s92"]
+    if ldsq:
+        L.append(f"v_xor_b32 {CANDC}, %[pp], {CANDC}")
+    # ---- election, exchange, the one exit test ----
+    # ELO's last writer is a v_dot2 (or the penalty form's v_add): three instructions go in front of its first reader
+    WQr = WQ if cheap else ("%[winq]" if not pen else LIMV)
+    L += [
+        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]",      # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
+        f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
+        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
+    ] + ([
+        f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc",       # a marked candidate's rank: what it provably costs, less one
+        f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc",   # ... and if that wins, the slice is abandoned
+        f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc",            # (diagnostics: marked (candidate, slice) pairs of this call)
+    ] if cheap else [
+        f"v_or_b32 {SHI}, %[sfsh], {SHI}",
+    ]) + [
+        f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
+    ] + ([f"v_or_b32 {SHI}, %[sfsh], {SHI}"] if cheap else [f"v_add_u32 {OCUR}, 8, {OCUR}"]) + [
+        f"v_add_u32 {TCUR}, 48, {TCUR}",
+        dpp(M, 4),
+        reads[0],
+        reads[1],
+        dpp(M, 2),
+        reads[2],
+        f"v_add_u32 {OCUR}, 8, {OCUR}" if cheap else "s_nop 0",
+        dpp(M, 1),
+        f"v_cmp_eq_u32 vcc, {K1}, {M}",
+        f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
+        f"ds_write_b128 {CANDC}, v[84:87]",
+        f"ds_write_b128 {CANDC}, {SLOT2} offset:16",
+        dpp(K2, 8),
+        f"v_cmp_le_u32 vcc, s94, {M}",                       # is the best rank its true rank?  (see spec_rank_pair)
+        f"v_cndmask_b32 {LQ}, {LIMV if pen else '%[limq]'}, {CH_BIG}, vcc",
+        dpp(K2, 4),
+        "s_add_u32 %[done], %[done], 1",
+        "s_nop 0" if ldsq else f"v_mov_b32 {N['acca']}, 0",  # the next slice's word (pk_step: acc_cleared)
+        dpp(K2, 2),
+        "s_nop 0" if ldsq else f"v_mov_b32 {N['accb']}, 0",
+        "s_nop 0",
+        dpp(K2, 1),
+        f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {CANDC}",          # the winner's slot
+        f"ds_read_b128 v[84:87], {ADDR}",
+        f"ds_read_b128 {SLOT2}, {ADDR} offset:16",
+        f"v_cmp_eq_u32 vcc, {ADDR}, {CANDC}",
+        f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
+        f"v_cndmask_b32 {THR}, {LQ}, {WQr}, vcc",
+        f"ds_write_b64 {OADDR}, v[80:81]",
+        f"{cmp_ge} vcc, {QMV}, {THR}",                       # the one exit test (see above)
+        "s_cmp_lg_u64 vcc, 0",
+        "s_cselect_b32 %[tmp], -1, %[done]",
+        "s_cmp_lt_u32 %[tmp], %[n]",
+        "s_cbranch_scc1 Lqoa_top_%=",
+        "s_cmp_lg_u32 %[tmp], -1",
+        "s_cbranch_scc1 Lqoa_end_%=",                        # all n slices done
+        "s_sub_u32 %[done], %[done], 1",                     # abandoned: the slice's entry state comes back
+        f"ds_read_b128 v[84:87], {PADDR}",
+        "Lqoa_end_%=:",
+        "s_waitcnt lgkmcnt(0)",
+    ] + (["s_mov_b32 %[tb], s90", "s_mov_b32 %[tt], s91"] if stamps else [])
     return L
 
 
@@ -815,9 +903,11 @@ INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaud
 
 def main():
     out, counts = render(verbose=True)
-    with open(INC_PATH, "w") as f:
+    path = os.environ.get("QOA_GEN_OUT", INC_PATH)           # (lab variants go elsewhere)
+    assert not LAB or path != INC_PATH, "QOA_GEN_LAB variants must not overwrite the product's texts"
+    with open(path, "w") as f:
         f.write(out)
-    print(f"wrote {INC_PATH}: " + " + ".join(str(c) for c in counts) + " lines")
+    print(f"wrote {path}: " + " + ".join(str(c) for c in counts) + " lines")
 
 
 if __name__ == "__main__":

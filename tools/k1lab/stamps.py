@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Where K1's slice time goes (lab build with in-kernel cycle stamps: tools/k1lab/build_lab.sh stamps stamps -DQOA_LAB_STAMPS).
+Run on the GPU box: QOAUDIO_AMD_LIB=$PWD/tools/k1lab/bin/lib_stamps.so python tools/k1lab/stamps.py [frames [clips]]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from qoaudio_amd import batch, synth, _lib  # noqa: E402
+import qoaudio_amd as gpu  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n_clips, ch = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 2
+samples = frames * 5120
+pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda")
+per, enc = samples * ch, gpu.encoded_size(ch, samples)
+clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
+plan = batch.EncodePlan(clips, batch.PLAN_COUNTERS)
+out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
+plan.run(pcm.view(-1), out)
+torch.cuda.synchronize()
+buf = (ctypes.c_uint64 * 12)()
+lib = _lib.lib()
+lib.qoa_encode_plan_counters(plan._h, buf, 12)
+c = list(buf)
+waves = n_clips * ch // 4
+ws = waves * frames * 256
+print("counters", c[:8])
+print(f"per wave-slice: steps {c[8] / ws:.1f} cycles, rest of the slice loop {c[9] / ws:.1f}, statement {c[10] / ws:.1f}, "
+      f"kernel {c[11] / ws:.1f}  (each stamp costs its own latency: two per slice)")
