@@ -536,14 +536,29 @@ constexpr unsigned kCheapCooldownBlocks = 4; // blocks on the exact-quotient for
 constexpr int kSliceDwords = 12;
 constexpr int kTileInts = (kBlockSlices + 1) * kSliceDwords;
 
+// Where lanes whose slice is not wholly inside the clip point their prefetch (20 samples x 8 channels of zeros).
+__device__ unsigned short g_prefetch_pad[20 * 8]; // (zero-initialised; not const: a constant-address-space pointer would turn the loads into flat ones)
+
+// Prefetch of one slice per lane, a block ahead: 20 loads off ONE address (sample t of this channel is p[t * NCH]: the
+// offsets are immediates), nothing per sample but the load.  Round 2 clamped every sample's index to the clip's last
+// sample -- ~10 VALU per sample, 200 per lane and block, 2 % of the kernel -- for the sake of the one partial slice a clip
+// can end with.  Now a lane whose slice is not wholly inside the clip prefetches a pad of zeros instead and
+// load_partial_slice() fetches that slice when its block begins (once per chain).
+// v[k] = samples (2k, 2k+1) of the slice as an i16 pair, the earlier one in the low half.
 template <int NCH>
 __device__ __forceinline__ void load_block_lane(const int16_t *__restrict__ p, unsigned slice_idx, unsigned samples,
                                                 unsigned (&v)[10]) {
-    // p = this channel's sample 0; sample t is p[t*NCH].  Indices past the clip end are clamped to its
-    // last sample: the values are never used (the tail path stops at the slice length).
-    // Branch-free on purpose: an if/else here makes the values a phi of vectors, which hipcc keeps
-    // as a register tuple and guards with vmcnt waits inside the slice loop.
-    // v[k] = samples (2k, 2k+1) of the slice as an i16 pair, the earlier one in the low half.
+    const unsigned long long base = (unsigned long long)slice_idx * 20u;
+    const unsigned short *q = base + 20u <= samples ? (const unsigned short *)p + base * NCH : g_prefetch_pad;
+#pragma unroll
+    for (int k = 0; k < 10; k++) v[k] = (unsigned)q[2 * k * NCH] | ((unsigned)q[(2 * k + 1) * NCH] << 16);
+}
+
+// The partial slice a clip may end with (1..19 samples): indices past the clip end are clamped to its last sample (the
+// values are never used: the tail path stops at the slice length).
+template <int NCH>
+__device__ __forceinline__ void load_partial_slice(const int16_t *__restrict__ p, unsigned slice_idx, unsigned samples,
+                                                unsigned (&v)[10]) {
     const unsigned long long base = (unsigned long long)slice_idx * 20u;
     const unsigned long long last = samples - 1u;
 #pragma unroll
@@ -694,6 +709,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     for (unsigned blk = 0; blk < nblocks; blk++) {
         // ---------------- block top: every vector-memory instruction of the loop lives here ----------------
         {
+            const unsigned long long s0 = ((unsigned long long)blk * kBlockSlices + (unsigned)sf) * 20u;
+            if (s0 < samples && s0 + 20u > samples) load_partial_slice<NCH>(p, blk * kBlockSlices + (unsigned)sf, samples, pre);
             int *dst = tile + sf * kSliceDwords; // needs the prefetched samples: the only vmcnt wait of the loop
             ((uint4 *)dst)[0] = make_uint4(marked_bound(pre), 0u, pre[0], pre[1]);
             ((uint4 *)dst)[1] = make_uint4(pre[2], pre[3], pre[4], pre[5]);
