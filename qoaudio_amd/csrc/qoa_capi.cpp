@@ -137,7 +137,7 @@ struct EncGroup {
 };
 
 #ifdef QOA_LAB_STAMPS
-constexpr size_t kCounters = 12; // + the timing experiment's four (tools/k1lab/stamps.sh)
+constexpr size_t kCounters = 17; // + the timing experiment's (tools/k1lab/stamps.sh)
 #else
 constexpr size_t kCounters = 8; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
 #endif

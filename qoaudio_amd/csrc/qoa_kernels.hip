@@ -544,14 +544,25 @@ __device__ unsigned short g_prefetch_pad[20 * 8]; // (zero-initialised; not cons
 // sample -- ~10 VALU per sample, 200 per lane and block, 2 % of the kernel -- for the sake of the one partial slice a clip
 // can end with.  Now a lane whose slice is not wholly inside the clip prefetches a pad of zeros instead and
 // load_partial_slice() fetches that slice when its block begins (once per chain).
-// v[k] = samples (2k, 2k+1) of the slice as an i16 pair, the earlier one in the low half.
+// raw[i] = sample i of the slice (zero-extended); pair_block_lane() makes the i16 pairs of them where they are consumed.
 template <int NCH>
 __device__ __forceinline__ void load_block_lane(const int16_t *__restrict__ p, unsigned slice_idx, unsigned samples,
-                                                unsigned (&v)[10]) {
+                                                unsigned (&raw)[20]) {
     const unsigned long long base = (unsigned long long)slice_idx * 20u;
     const unsigned short *q = base + 20u <= samples ? (const unsigned short *)p + base * NCH : g_prefetch_pad;
 #pragma unroll
-    for (int k = 0; k < 10; k++) v[k] = (unsigned)q[2 * k * NCH] | ((unsigned)q[(2 * k + 1) * NCH] << 16);
+    for (int i = 0; i < 20; i++) raw[i] = q[i * NCH];
+}
+
+// v[k] = samples (2k, 2k+1) of the slice as an i16 pair, the earlier one in the low half.  The empty asm pins the pairing
+// -- and with it the wait for the loads -- to this place: left to itself hipcc hoists it to the first join behind the
+// loads, which for a block that takes the ladder is right behind them (their whole latency exposed, +4 % on noise).
+__device__ __forceinline__ void pair_block_lane(unsigned (&raw)[20], unsigned (&v)[10]) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        asm volatile("" : "+v"(raw[2 * k]), "+v"(raw[2 * k + 1]));
+        v[k] = raw[2 * k] | (raw[2 * k + 1] << 16);
+    }
 }
 
 // The partial slice a clip may end with (1..19 samples): indices past the clip end are clamped to its last sample (the
@@ -676,9 +687,16 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // material that defeats a form does so for long stretches (tonal passages keep the weights at the penalty threshold for
     // seconds; full-scale noise and clipped material never leave it), an isolated miss costs the rest of its block only.
     unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0, pk_cooldown = 0, pk_streak = 0;
+    // The steady state: no form sitting out, no streak running, every chain of the wave packed -- then a whole block goes to the
+    // cheap-quotient statement behind ONE test (a lone wavefront pays ~25 cycles per branch and the ladder below has a dozen:
+    // ~700 cycles per block, 1.6 % of the kernel, measured with tools/k1lab/stamps.py).  ok_blocks = the lane's number of whole
+    // blocks while steady, 0 otherwise; recomputed whenever the ladder has run.
+    const bool steady_flags = allow_packed && allow_spec && allow_cheap && !lds_tables && !force_tail_path;
+    const unsigned full_blocks = samples / (20u * kBlockSlices);
 
 #ifdef QOA_LAB_STAMPS // stats[8..11]: wave cycles in the steps / rest of the slice loop / the whole statement / the kernel
-    unsigned long long lab_acc[3] = {0, 0, 0};
+    unsigned long long lab_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lab_t = 0;
+#define QOA_LAB_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); lab_acc[i] += t_ - lab_t; lab_t = t_; }
     const unsigned long long lab_k0 = __builtin_readcyclecounter();
 #endif
     Lms st;
@@ -694,6 +712,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // The chain's state lives in `pk` while `packed` (st is then stale), in `st` otherwise.
     PkLms pk;
     bool packed = pk_try_pack(st, pk) && allow_packed;
+    unsigned ok_blocks = steady_flags && packed ? full_blocks : 0u;
 
     uint8_t *o = out + ch.out_off;
     if (ch.flags & 1u) { // file header "qoaf" + samples, big-endian (src/lib.rs:382-385)
@@ -702,20 +721,28 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     }
     constexpr unsigned kFrameBytes = 8 + 16 * NCH + 8 * kSlicesPerFrame * NCH; // a full frame
 
-    unsigned pre[10];                  // lane j: samples of slice 16*(blk+1)+j (i16 pairs), in flight during block blk
+    unsigned raw[20];                  // lane j: samples of slice 16*(blk+1)+j, in flight during block blk
     // the winning slice of row 16*blk+j waits in out_tile[j] (LDS) for the flush at the next block top
-    load_block_lane<NCH>(p, (unsigned)sf, samples, pre);
+    load_block_lane<NCH>(p, (unsigned)sf, samples, raw);
 
+#ifndef QOA_LAB_STAMPS
+#define QOA_LAB_MARK(i)
+#else
+    lab_t = __builtin_readcyclecounter();
+#endif
     for (unsigned blk = 0; blk < nblocks; blk++) {
         // ---------------- block top: every vector-memory instruction of the loop lives here ----------------
         {
             const unsigned long long s0 = ((unsigned long long)blk * kBlockSlices + (unsigned)sf) * 20u;
+            unsigned pre[10];
+            pair_block_lane(raw, pre);
             if (s0 < samples && s0 + 20u > samples) load_partial_slice<NCH>(p, blk * kBlockSlices + (unsigned)sf, samples, pre);
             int *dst = tile + sf * kSliceDwords; // needs the prefetched samples: the only vmcnt wait of the loop
             ((uint4 *)dst)[0] = make_uint4(marked_bound(pre), 0u, pre[0], pre[1]);
             ((uint4 *)dst)[1] = make_uint4(pre[2], pre[3], pre[4], pre[5]);
             ((uint4 *)dst)[2] = make_uint4(pre[6], pre[7], pre[8], pre[9]);
         }
+        QOA_LAB_MARK(3) // (lab) [3] loop back edge + tile store
         if (blk > 0) { // flush the previous block's 16 slices (always a full block)
             const unsigned k = (blk - 1) * kBlockSlices + (unsigned)sf;
             uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
@@ -739,17 +766,34 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             d[1] = make_uint2(bswap32(((unsigned)st.w0 << 16) | ((unsigned)st.w1 & 0xffffu)),
                               bswap32(((unsigned)st.w2 << 16) | ((unsigned)st.w3 & 0xffffu)));
         }
-        load_block_lane<NCH>(p, (blk + 1) * kBlockSlices + (unsigned)sf, samples, pre); // prefetch next block
+        QOA_LAB_MARK(4) // [4] flush + frame header
+        load_block_lane<NCH>(p, (blk + 1) * kBlockSlices + (unsigned)sf, samples, raw); // prefetch next block
+        QOA_LAB_MARK(5) // [5] prefetch issue
 
         // ---------------- 16 slices, no vector memory ----------------
         const unsigned k0 = blk * kBlockSlices;
         const unsigned nj = min(nslices - k0, (unsigned)kBlockSlices);
         unsigned j = 0;
-        {   // a block whose 16 slices are full in every chain of the wave: block statements
+        typedef __attribute__((address_space(3))) int *lds_int;
+        const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
+        bool cheap_declined = false; // the steady path's statement has already declined slice j
+        if (__builtin_amdgcn_ballot_w64(blk >= ok_blocks) == 0ull) { // steady: the whole block on the cheap-quotient statement
+            unsigned marked;
+#ifdef QOA_LAB_STAMPS
+            const unsigned long long lab_c0 = __builtin_readcyclecounter();
+            j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk, &marked,
+                                     lab_acc);
+            lab_acc[2] += __builtin_readcyclecounter() - lab_c0;
+#else
+            j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk, &marked);
+#endif
+            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+            if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
+            cheap_declined = j < kBlockSlices;
+        }
+        if (j < kBlockSlices) { // the ladder: a block whose 16 slices are full in every chain of the wave goes to block statements
             const bool whole = !force_tail_path && (unsigned long long)(k0 + kBlockSlices) * 20u <= samples;
             const bool block_ok = __builtin_amdgcn_ballot_w64(!whole) == 0ull;
-            typedef __attribute__((address_space(3))) int *lds_int;
-            const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
             // the packed forms, while every chain of the wave is packed and they are not sitting out
             if (block_ok && pk_cooldown == 0 && __builtin_amdgcn_ballot_w64(!packed) == 0ull) {
                 if (allow_spec && spec_cooldown == 0) {
@@ -763,18 +807,14 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                         while (j < kBlockSlices && proven) {
                             const bool cheap = allow_cheap && cheap_cooldown == 0;
                             if (cheap) {
-                                unsigned marked;
-#ifdef QOA_LAB_STAMPS
-                                const unsigned long long lab_c0 = __builtin_readcyclecounter();
-                                j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
-                                                          dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked, lab_acc);
-                                lab_acc[2] += __builtin_readcyclecounter() - lab_c0;
-#else
-                                j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
-                                                          dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
-#endif
-                                j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-                                if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
+                                if (!cheap_declined) {
+                                    unsigned marked;
+                                    j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
+                                                              dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
+                                    j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+                                    if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
+                                }
+                                cheap_declined = false;
                                 if (j == kBlockSlices) break;
                                 if (stats && sf == 0) atomicAdd(&stats[3], 1ull);
                                 if (blk - last_cheap_decline <= 1u) cheap_cooldown = kCheapCooldownBlocks + 1;
@@ -837,7 +877,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             if (cheap_cooldown) cheap_cooldown--;
             if (pen_cooldown) pen_cooldown--;
             if (pk_cooldown) pk_cooldown--;
+            const unsigned unsteady = spec_cooldown | cheap_cooldown | pk_cooldown | spec_streak | (blk - last_cheap_decline <= 1u ? 1u : 0u);
+            ok_blocks = steady_flags && packed && __builtin_amdgcn_readfirstlane((int)unsteady) == 0 ? full_blocks : 0u;
         }
+        QOA_LAB_MARK(6) // [6] the block statements and their dispatch
         for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);
             const bool full = (len == 20) && !force_tail_path;
@@ -913,6 +956,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     if (stats && lane == 0) {
         atomicAdd(&stats[8], lab_acc[0]); atomicAdd(&stats[9], lab_acc[1]); atomicAdd(&stats[10], lab_acc[2]);
         atomicAdd(&stats[11], __builtin_readcyclecounter() - lab_k0);
+        for (int i = 3; i < 8; i++) atomicAdd(&stats[9 + i], lab_acc[i]);
     }
 #endif
 }

@@ -21,12 +21,15 @@ plan = batch.EncodePlan(clips, batch.PLAN_COUNTERS)
 out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
 plan.run(pcm.view(-1), out)
 torch.cuda.synchronize()
-buf = (ctypes.c_uint64 * 12)()
+buf = (ctypes.c_uint64 * 17)()
 lib = _lib.lib()
-lib.qoa_encode_plan_counters(plan._h, buf, 12)
+lib.qoa_encode_plan_counters(plan._h, buf, 17)
 c = list(buf)
 waves = n_clips * ch // 4
 ws = waves * frames * 256
 print("counters", c[:8])
 print(f"per wave-slice: steps {c[8] / ws:.1f} cycles, rest of the slice loop {c[9] / ws:.1f}, statement {c[10] / ws:.1f}, "
       f"kernel {c[11] / ws:.1f}  (each stamp costs its own latency: two per slice)")
+wb = ws / 16
+print(f"per wave-block: back edge + tile store {c[12] / wb:.0f}, flush + header {c[13] / wb:.0f}, prefetch issue {c[14] / wb:.0f}, "
+      f"statements + dispatch {c[15] / wb:.0f} (statement alone {c[10] / wb:.0f})")
