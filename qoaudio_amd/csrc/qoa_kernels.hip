@@ -732,6 +732,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
 #endif
     for (unsigned blk = 0; blk < nblocks; blk++) {
         // ---------------- block top: every vector-memory instruction of the loop lives here ----------------
+#ifdef QOA_LAB_NO_BLOCKTOP // timing experiment: what would the kernel cost if another wavefront did the block top?  (wrong bytes)
+        if (blk == 0)
+#endif
         {
             const unsigned long long s0 = ((unsigned long long)blk * kBlockSlices + (unsigned)sf) * 20u;
             unsigned pre[10];
@@ -743,13 +746,22 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             ((uint4 *)dst)[2] = make_uint4(pre[6], pre[7], pre[8], pre[9]);
         }
         QOA_LAB_MARK(3) // (lab) [3] loop back edge + tile store
-        if (blk > 0) { // flush the previous block's 16 slices (always a full block)
+#ifdef QOA_LAB_NO_BLOCKTOP
+        if (blk == 1)
+#else
+        if (blk > 0)
+#endif
+        { // flush the previous block's 16 slices (always a full block)
             const unsigned k = (blk - 1) * kBlockSlices + (unsigned)sf;
             uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
             const uint2 kept = out_tile[sf];
             *(uint2 *)so = make_uint2(bswap32(kept.x), bswap32(kept.y));
         }
+#ifdef QOA_LAB_NO_BLOCKTOP
+        if (blk == 0 && sf == 0) {
+#else
         if ((blk & 15u) == 0 && sf == 0) {
+#endif
             // frame header + this channel's LMS state at frame entry (src/lib.rs:448-466)
             const unsigned frame = blk >> 4;
             uint8_t *fo = o + (size_t)frame * kFrameBytes;
@@ -767,6 +779,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                               bswap32(((unsigned)st.w2 << 16) | ((unsigned)st.w3 & 0xffffu)));
         }
         QOA_LAB_MARK(4) // [4] flush + frame header
+#ifdef QOA_LAB_NO_BLOCKTOP
+        if (blk == 0)
+#endif
         load_block_lane<NCH>(p, (blk + 1) * kBlockSlices + (unsigned)sf, samples, raw); // prefetch next block
         QOA_LAB_MARK(5) // [5] prefetch issue
 

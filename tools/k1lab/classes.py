@@ -27,6 +27,15 @@ for kind in kinds:
         song = torch.from_numpy(fp.reshape(-1, 2))
         offs = (np.arange(n_clips) * 997 * 20) % (song.shape[0] - samples)
         pcm = torch.stack([song[o:o + samples] for o in offs]).cuda().contiguous()
+    elif kind == "periodic":  # period = one 16-slice block (for lab builds that reuse the first tile: -DQOA_LAB_NO_BLOCKTOP)
+        import numpy as np
+        t = np.arange(320)
+        rng = np.random.default_rng(5)
+        x = np.zeros((n_clips, 320, ch))
+        for h in (1, 2, 3, 5, 8, 13):
+            ph = rng.uniform(0, 2 * np.pi, (n_clips, 1, ch))
+            x += (3000.0 / h) * np.sin(2 * np.pi * h * t[None, :, None] / 320 + ph)
+        pcm = torch.from_numpy(np.rint(np.tile(x, (1, samples // 320, 1))).astype(np.int16)).cuda()
     elif kind == "loud":  # the music class amplified 3x into clipping
         pcm = (synth.make_clips(n_clips, samples, ch, 44100, device="cuda").to(torch.int32) * 3).clamp_(-32768, 32767).to(torch.int16)
     else:
