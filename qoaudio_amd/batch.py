@@ -22,6 +22,8 @@ PLAN_NO_LDS_TABLES = 128
 PLAN_EXACT_QUOTIENT = 256
 PLAN_NO_PENALTY_FORM = 1024
 PLAN_NO_BLOCK32 = 2048
+PLAN_NO_HELPER = 4096
+PLAN_FORCE_HELPER = 8192
 PLAN_COUNTERS = 512  # count the fast paths' fall-backs (EncodePlan.stats / .counters); off by default: no atomics in the kernel
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 

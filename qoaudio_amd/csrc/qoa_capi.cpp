@@ -257,13 +257,15 @@ extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t
 
 // kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
 // bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table,
-// bit5 no cheap-quotient speculative steps, bit6 no penalty form, bit7 no 32-bit block statement
+// bit5 no cheap-quotient speculative steps, bit6 no penalty form, bit7 no 32-bit block statement,
+// bit8 no helper wavefronts, bit9 helper wavefronts whatever the launch size
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) |
                       ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) |
                       ((plan->flags & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u) | ((plan->flags & QOA_PLAN_NO_PENALTY_FORM) ? 64u : 0u) |
-                      ((plan->flags & QOA_PLAN_NO_BLOCK32) ? 128u : 0u);
+                      ((plan->flags & QOA_PLAN_NO_BLOCK32) ? 128u : 0u) | ((plan->flags & QOA_PLAN_NO_HELPER) ? 256u : 0u) |
+                      ((plan->flags & QOA_PLAN_FORCE_HELPER) ? 512u : 0u);
     for (auto *g : plan->groups) {
         const unsigned lds = plan_lds_form(plan->flags, g) ? 16u : 0u;
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,

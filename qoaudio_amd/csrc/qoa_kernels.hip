@@ -527,6 +527,7 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
 // headers / LMS dumps are written at block tops too.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlockSlices = 16;
+constexpr unsigned kHelperMaxWaves = 512; // launches up to this many compute wavefronts get helper wavefronts (1024 SIMDs)
 constexpr unsigned kSpecCooldownBlocks = 4; // blocks on the full step form after a speculation miss (misses cluster)
 constexpr unsigned kCheapCooldownBlocks = 4; // blocks on the exact-quotient form once the cheap-quotient form declined slices
                                              // in two consecutive blocks (or twice in one)
@@ -610,7 +611,18 @@ __device__ __forceinline__ void unpack_tile_slice(const int *src, int (&smp)[20]
     }
 }
 
-template <int CPW, int NCH>
+// The two wavefronts of a HELPER workgroup synchronise once per block: LDS traffic done, then the barrier.
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// HELPER = true (launches that leave SIMDs idle: config 3 has wavefronts for half of them): a workgroup is ONE compute
+// wavefront plus a helper wavefront on another SIMD of the CU that does everything the block top used to do -- prefetch the
+// next block's samples, compute the marked bounds, fill the (now double-buffered) LDS tile, flush the previous block's slice
+// words, write frame headers from the LMS state the compute wavefront parks in LDS at frame starts.  The compute wavefront
+// touches no vector memory in its loop and pays one s_barrier per block instead of ~1,200 cycles of block top (3.2 % of the
+// kernel: tools/k1lab, QOA_LAB_NO_BLOCKTOP on the periodic class).  Barrier b separates the compute wavefront's blocks
+// b - 1 and b: before it the helper has filled tile[b & 1] and flushed out_tile[b & 1] (block b - 2's words); after it the
+// helper flushes out_tile[(b - 1) & 1], fills tile[(b + 1) & 1] and writes frame b / 16's header.
+template <int CPW, int NCH, bool HELPER = false>
 __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restrict__ pcm, uint8_t *__restrict__ out,
                                                          const EncChain *__restrict__ chains, unsigned n_chains,
                                                          int32_t *__restrict__ lms_state, unsigned flags,
@@ -632,6 +644,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // quantiser + dequantiser table of the LDS-table step form (flags bit 4): [sf][scaled + 8] = dequant & 0xffff | code << 29
     // with code = QOA_QUANT_TAB[scaled + 8] (src/lib.rs:22), dequant = QOA_DEQUANT_TAB[sf][code] (:847-864)
     __shared__ unsigned s_qtab[16][17];
+    __shared__ int s_hdr[CPW][8]; // HELPER: a chain's LMS state at frame entry, parked for the helper's frame header
     if (flags & 16u) {
         for (unsigned t = threadIdx.x; t < 16 * 17; t += blockDim.x) {
             const unsigned tsf = t / 17, idx = t % 17;
@@ -646,16 +659,21 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const unsigned grp = lane >> 4;
     if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle
     const unsigned wave_in_block = threadIdx.x >> 6;
-    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const bool is_helper = HELPER && wave_in_block == 1;    // (both wavefronts of a HELPER workgroup serve the same chains)
+    const unsigned slot = HELPER ? 0u : wave_in_block;      // the LDS slot set of this wavefront's chains
+    const unsigned wave = HELPER ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const unsigned chain_id = wave * CPW + grp;
     if (chain_id >= n_chains) return;
     const int sf = (int)(lane & 15u);
     const unsigned row_base = lane & ~15u;
-    int *tile = s_smp + (wave_in_block * CPW + grp) * kTileInts;
-    uint2 *out_tile = s_out[wave_in_block][grp];
+    // HELPER: tiles are double-buffered (block b uses buffer b & 1; the second buffer is the slot set of "wavefront 1")
+    int *const tile_buf[2] = {s_smp + (slot * CPW + grp) * kTileInts, s_smp + ((HELPER ? 1u : slot) * CPW + grp) * kTileInts};
+    uint2 *const out_buf[2] = {s_out[slot][grp], s_out[HELPER ? 1u : slot][grp]};
+    int *tile = tile_buf[0];
+    uint2 *out_tile = out_buf[0];
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[0][wave_in_block][grp][sf][0];
-    const unsigned outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
+    const unsigned cand_addr = (unsigned)(size_t)(lds_ptr)&s_cand[0][slot][grp][sf][0];
+    unsigned outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
 
     const EncChain ch = chains[chain_id];
     if (ch.samples == 0) return; // a clip that has no frames in this time slice (host pipeline): state untouched
@@ -716,14 +734,68 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
 
     uint8_t *o = out + ch.out_off;
     if (ch.flags & 1u) { // file header "qoaf" + samples, big-endian (src/lib.rs:382-385)
-        if (sf == 0 && ch.channel == 0) *(uint2 *)o = make_uint2(bswap32(kMagic), bswap32(ch.total_samples));
+        if (sf == 0 && ch.channel == 0 && (!HELPER || is_helper)) *(uint2 *)o = make_uint2(bswap32(kMagic), bswap32(ch.total_samples));
         o += 8;
     }
     constexpr unsigned kFrameBytes = 8 + 16 * NCH + 8 * kSlicesPerFrame * NCH; // a full frame
 
+    // ---- the pieces of the block top (the classic loop runs them itself, a HELPER workgroup's second wavefront for it) ----
+    auto fill_tile = [&](int *t, unsigned b, unsigned (&rw)[20]) { // rw = load_block_lane() of slice 16 b + sf
+        const unsigned long long s0 = ((unsigned long long)b * kBlockSlices + (unsigned)sf) * 20u;
+        unsigned pre[10];
+        pair_block_lane(rw, pre);
+        if (s0 < samples && s0 + 20u > samples) load_partial_slice<NCH>(p, b * kBlockSlices + (unsigned)sf, samples, pre);
+        int *dst = t + sf * kSliceDwords; // needs the prefetched samples: the only vmcnt wait of the loop
+        ((uint4 *)dst)[0] = make_uint4(marked_bound(pre), 0u, pre[0], pre[1]);
+        ((uint4 *)dst)[1] = make_uint4(pre[2], pre[3], pre[4], pre[5]);
+        ((uint4 *)dst)[2] = make_uint4(pre[6], pre[7], pre[8], pre[9]);
+    };
+    auto flush_block = [&](const uint2 *ot, unsigned b) { // the winning slice words of block b (lane j: row 16 b + j)
+        const unsigned k = b * kBlockSlices + (unsigned)sf;
+        if (k < nslices) {
+            uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
+            const uint2 kept = ot[sf];
+            *(uint2 *)so = make_uint2(bswap32(kept.x), bswap32(kept.y));
+        }
+    };
+    auto frame_header = [&](unsigned b, int h0, int h1, int h2, int h3, int w0, int w1, int w2, int w3) {
+        // frame header + this channel's LMS state at frame entry (src/lib.rs:448-466); block b = 16 * frame, lane sf == 0
+        const unsigned frame = b >> 4;
+        uint8_t *fo = o + (size_t)frame * kFrameBytes;
+        if (ch.channel == 0) {
+            unsigned frame_len = min(samples - frame * (unsigned)kFrameLen, (unsigned)kFrameLen);
+            unsigned fslices = (frame_len + 19u) / 20u;
+            unsigned fsize = (8u + 16u * NCH + 8u * fslices * NCH) & 0xffffu;
+            *(uint2 *)fo = make_uint2(bswap32(ch.hdr_hi), bswap32((frame_len << 16) | fsize));
+        }
+        uint2 *d = (uint2 *)(fo + 8 + 16 * ch.channel);
+        d[0] = make_uint2(bswap32(((unsigned)h0 << 16) | ((unsigned)h1 & 0xffffu)), bswap32(((unsigned)h2 << 16) | ((unsigned)h3 & 0xffffu)));
+        d[1] = make_uint2(bswap32(((unsigned)w0 << 16) | ((unsigned)w1 & 0xffffu)), bswap32(((unsigned)w2 << 16) | ((unsigned)w3 & 0xffffu)));
+    };
+
     unsigned raw[20];                  // lane j: samples of slice 16*(blk+1)+j, in flight during block blk
-    // the winning slice of row 16*blk+j waits in out_tile[j] (LDS) for the flush at the next block top
-    load_block_lane<NCH>(p, (unsigned)sf, samples, raw);
+    if constexpr (HELPER) {
+        if (is_helper) {
+            load_block_lane<NCH>(p, (unsigned)sf, samples, raw);
+            fill_tile(tile_buf[0], 0, raw);
+            for (unsigned b = 0; __builtin_amdgcn_ballot_w64(b <= nblocks) != 0ull; b++) { // one barrier more than the longest chain has blocks
+                pair_barrier();
+                if (b < nblocks && (b & 15u) == 0 && sf == 0) {
+                    const int *h = s_hdr[grp];
+                    frame_header(b, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+                }
+                if (b >= 1 && b <= nblocks) flush_block(out_buf[(b - 1) & 1u], b - 1);
+                if (b + 1 < nblocks) {
+                    load_block_lane<NCH>(p, (b + 1) * kBlockSlices + (unsigned)sf, samples, raw);
+                    fill_tile(tile_buf[(b + 1) & 1u], b + 1, raw);
+                }
+            }
+            return;
+        }
+    } else {
+        // the winning slice of row 16*blk+j waits in out_tile[j] (LDS) for the flush at the next block top
+        load_block_lane<NCH>(p, (unsigned)sf, samples, raw);
+    }
 
 #ifndef QOA_LAB_STAMPS
 #define QOA_LAB_MARK(i)
@@ -732,58 +804,44 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
 #endif
     for (unsigned blk = 0; blk < nblocks; blk++) {
         // ---------------- block top: every vector-memory instruction of the loop lives here ----------------
-#ifdef QOA_LAB_NO_BLOCKTOP // timing experiment: what would the kernel cost if another wavefront did the block top?  (wrong bytes)
-        if (blk == 0)
-#endif
-        {
-            const unsigned long long s0 = ((unsigned long long)blk * kBlockSlices + (unsigned)sf) * 20u;
-            unsigned pre[10];
-            pair_block_lane(raw, pre);
-            if (s0 < samples && s0 + 20u > samples) load_partial_slice<NCH>(p, blk * kBlockSlices + (unsigned)sf, samples, pre);
-            int *dst = tile + sf * kSliceDwords; // needs the prefetched samples: the only vmcnt wait of the loop
-            ((uint4 *)dst)[0] = make_uint4(marked_bound(pre), 0u, pre[0], pre[1]);
-            ((uint4 *)dst)[1] = make_uint4(pre[2], pre[3], pre[4], pre[5]);
-            ((uint4 *)dst)[2] = make_uint4(pre[6], pre[7], pre[8], pre[9]);
-        }
-        QOA_LAB_MARK(3) // (lab) [3] loop back edge + tile store
-#ifdef QOA_LAB_NO_BLOCKTOP
-        if (blk == 1)
-#else
-        if (blk > 0)
-#endif
-        { // flush the previous block's 16 slices (always a full block)
-            const unsigned k = (blk - 1) * kBlockSlices + (unsigned)sf;
-            uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
-            const uint2 kept = out_tile[sf];
-            *(uint2 *)so = make_uint2(bswap32(kept.x), bswap32(kept.y));
-        }
-#ifdef QOA_LAB_NO_BLOCKTOP
-        if (blk == 0 && sf == 0) {
-#else
-        if ((blk & 15u) == 0 && sf == 0) {
-#endif
-            // frame header + this channel's LMS state at frame entry (src/lib.rs:448-466)
-            const unsigned frame = blk >> 4;
-            uint8_t *fo = o + (size_t)frame * kFrameBytes;
-            if (ch.channel == 0) {
-                unsigned frame_len = min(samples - frame * (unsigned)kFrameLen, (unsigned)kFrameLen);
-                unsigned fslices = (frame_len + 19u) / 20u;
-                unsigned fsize = (8u + 16u * NCH + 8u * fslices * NCH) & 0xffffu;
-                *(uint2 *)fo = make_uint2(bswap32(ch.hdr_hi), bswap32((frame_len << 16) | fsize));
+        if constexpr (HELPER) {
+            if ((blk & 15u) == 0 && sf == 0) { // park the state at frame entry for the helper's frame header
+                if (packed) pk_unpack(pk, st);
+                int *h = s_hdr[grp];
+                h[0] = st.h0; h[1] = st.h1; h[2] = st.h2; h[3] = st.h3;
+                h[4] = st.w0; h[5] = st.w1; h[6] = st.w2; h[7] = st.w3;
             }
-            uint2 *d = (uint2 *)(fo + 8 + 16 * ch.channel);
-            if (packed) pk_unpack(pk, st);
-            d[0] = make_uint2(bswap32(((unsigned)st.h0 << 16) | ((unsigned)st.h1 & 0xffffu)),
-                              bswap32(((unsigned)st.h2 << 16) | ((unsigned)st.h3 & 0xffffu)));
-            d[1] = make_uint2(bswap32(((unsigned)st.w0 << 16) | ((unsigned)st.w1 & 0xffffu)),
-                              bswap32(((unsigned)st.w2 << 16) | ((unsigned)st.w3 & 0xffffu)));
-        }
-        QOA_LAB_MARK(4) // [4] flush + frame header
-#ifdef QOA_LAB_NO_BLOCKTOP
-        if (blk == 0)
+            pair_barrier();
+            tile = tile_buf[blk & 1u];
+            out_tile = out_buf[blk & 1u];
+            outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
+        } else {
+#ifdef QOA_LAB_NO_BLOCKTOP // timing experiment: what would the kernel cost if another wavefront did the block top?  (wrong bytes)
+            if (blk == 0)
 #endif
-        load_block_lane<NCH>(p, (blk + 1) * kBlockSlices + (unsigned)sf, samples, raw); // prefetch next block
-        QOA_LAB_MARK(5) // [5] prefetch issue
+            fill_tile(tile, blk, raw);
+            QOA_LAB_MARK(3) // (lab) [3] loop back edge + tile store
+#ifdef QOA_LAB_NO_BLOCKTOP
+            if (blk == 1)
+#else
+            if (blk > 0)
+#endif
+                flush_block(out_tile, blk - 1); // the previous block's 16 slices (always a full block)
+#ifdef QOA_LAB_NO_BLOCKTOP
+            if (blk == 0 && sf == 0) {
+#else
+            if ((blk & 15u) == 0 && sf == 0) {
+#endif
+                if (packed) pk_unpack(pk, st);
+                frame_header(blk, st.h0, st.h1, st.h2, st.h3, st.w0, st.w1, st.w2, st.w3);
+            }
+            QOA_LAB_MARK(4) // [4] flush + frame header
+#ifdef QOA_LAB_NO_BLOCKTOP
+            if (blk == 0)
+#endif
+            load_block_lane<NCH>(p, (blk + 1) * kBlockSlices + (unsigned)sf, samples, raw); // prefetch next block
+            QOA_LAB_MARK(5) // [5] prefetch issue
+        }
 
         // ---------------- 16 slices, no vector memory ----------------
         const unsigned k0 = blk * kBlockSlices;
@@ -953,13 +1011,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             packed = pk_try_pack(st, pk) && allow_packed;
         }
     }
-    { // flush the last (possibly partial) block
-        const unsigned k = (nblocks - 1) * kBlockSlices + (unsigned)sf;
-        if (k < nslices) {
-            uint8_t *so = o + (size_t)(k >> 8) * kFrameBytes + 8 + 16 * NCH + ((size_t)(k & 255u) * NCH + ch.channel) * 8;
-            const uint2 kept = out_tile[sf];
-            *(uint2 *)so = make_uint2(bswap32(kept.x), bswap32(kept.y));
-        }
+    if constexpr (HELPER) {
+        pair_barrier(); // the helper flushes the last block behind it
+    } else {
+        flush_block(out_tile, nblocks - 1); // the last (possibly partial) block
     }
     if (packed) pk_unpack(pk, st);
     if (sf == 0) {
@@ -1050,6 +1105,24 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
     // now 150-200).  From 4 wavefronts up the 4-wave workgroups stay: 8 single-wave workgroups on 8 CUs made the 8-channel
     // streaming call slower (0.48 vs 0.38 ms).
     unsigned waves = (n + CPW - 1) / CPW;
+    // A launch that leaves at least half of the chip's 1024 SIMDs idle gives every compute wavefront a helper wavefront
+    // (HELPER workgroups: see the kernel).  flags bit 8: never, bit 9: always (tests, experiments).
+    if constexpr (CPW == 4) {
+        const bool helper = (flags & 256u) == 0 && (waves <= kHelperMaxWaves || (flags & 512u) != 0);
+        if (helper) {
+            dim3 g(waves), b(128);
+#define QOA_LAUNCH(N)                                                                                                    \
+    case N:                                                                                                              \
+        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N, true>), g, b, 0, stream, pcm, out, chains, n, lms, flags, stats); \
+        break;
+            switch (nch) {
+                QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
+            default: return hipErrorInvalidValue;
+            }
+#undef QOA_LAUNCH
+            return hipGetLastError();
+        }
+    }
     const unsigned kWavesPerBlock = waves < 4 ? 1 : 4;
     unsigned blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     dim3 g(blocks), b(64 * kWavesPerBlock);

@@ -129,13 +129,16 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "generic", "step32", "step32_slices", "noblock32", "nospec", "exactq", "ldsq",
+@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "cpw4_classic", "cpw4_classic_step32", "cpw4_step32", "generic", "step32", "step32_slices", "noblock32", "nospec", "exactq", "ldsq",
                                    "ldsq_cpw1"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
-    fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,
+    fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,   # cpw4: helper wavefronts
+          "cpw4_classic": batch.PLAN_CPW_4 | batch.PLAN_NO_HELPER,
+          "cpw4_classic_step32": batch.PLAN_CPW_4 | batch.PLAN_NO_HELPER | batch.PLAN_FORCE_32BIT_STEP,
+          "cpw4_step32": batch.PLAN_CPW_4 | batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32,
           "generic": batch.PLAN_FORCE_GENERIC_PATH | batch.PLAN_CPW_4, "step32": batch.PLAN_FORCE_32BIT_STEP,
           "step32_slices": batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32, "noblock32": batch.PLAN_NO_BLOCK32,
           "nospec": batch.PLAN_NO_SPECULATION, "exactq": batch.PLAN_EXACT_QUOTIENT,
