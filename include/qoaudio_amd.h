@@ -138,7 +138,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_NO_PENALTY_FORM 1024u /* debug: where the speculative steps miss, go straight to the full form (same bytes) */
 #define QOA_PLAN_NO_BLOCK32 2048u       /* debug: slices the packed forms cannot take go one by one, not through the 32-bit block loop */
 #define QOA_PLAN_NO_HELPER 4096u        /* debug: no helper wavefronts (K1's two-wavefront workgroups for launches that leave SIMDs idle) */
-#define QOA_PLAN_FORCE_HELPER 8192u     /* debug: helper wavefronts whatever the launch size (4 chains per wavefront only) */
+#define QOA_PLAN_FORCE_HELPER 8192u     /* debug: helper wavefronts whatever the launch size */
 #define QOA_PLAN_COUNTERS 512u         /* count the fast paths' fall-backs (qoa_encode_plan_stats / _counters); without it the */
                                        /* kernel is handed no counter block and executes no atomic at all */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */

@@ -1107,7 +1107,7 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
     unsigned waves = (n + CPW - 1) / CPW;
     // A launch that leaves at least half of the chip's 1024 SIMDs idle gives every compute wavefront a helper wavefront
     // (HELPER workgroups: see the kernel).  flags bit 8: never, bit 9: always (tests, experiments).
-    if constexpr (CPW == 4) {
+    {
         const bool helper = (flags & 256u) == 0 && (waves <= kHelperMaxWaves || (flags & 512u) != 0);
         if (helper) {
             dim3 g(waves), b(128);

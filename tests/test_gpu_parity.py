@@ -129,13 +129,14 @@ def test_config5_eight_channel_streaming(gpu, oracle):
     assert bytes(out) == oracle.encode_all(x, ch, 48000, n)
 
 
-@pytest.mark.parametrize("flags", ["default", "cpw1", "cpw2", "cpw4", "cpw4_classic", "cpw4_classic_step32", "cpw4_step32", "generic", "step32", "step32_slices", "noblock32", "nospec", "exactq", "ldsq",
+@pytest.mark.parametrize("flags", ["default", "classic", "cpw1", "cpw2", "cpw2_classic", "cpw4", "cpw4_classic", "cpw4_classic_step32", "cpw4_step32", "generic", "step32", "step32_slices", "noblock32", "nospec", "exactq", "ldsq",
                                    "ldsq_cpw1"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
     from qoaudio_amd import batch
     fl = {"default": 0, "cpw1": batch.PLAN_CPW_1, "cpw2": batch.PLAN_CPW_2, "cpw4": batch.PLAN_CPW_4,   # cpw4: helper wavefronts
+          "classic": batch.PLAN_NO_HELPER, "cpw2_classic": batch.PLAN_CPW_2 | batch.PLAN_NO_HELPER,
           "cpw4_classic": batch.PLAN_CPW_4 | batch.PLAN_NO_HELPER,
           "cpw4_classic_step32": batch.PLAN_CPW_4 | batch.PLAN_NO_HELPER | batch.PLAN_FORCE_32BIT_STEP,
           "cpw4_step32": batch.PLAN_CPW_4 | batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32,
@@ -539,7 +540,8 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     pcm = torch.from_numpy(fixture_pcm).cuda()
     outs = []
     for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT,
-                  batch.PLAN_NO_PENALTY_FORM, batch.PLAN_NO_BLOCK32, batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32):
+                  batch.PLAN_NO_PENALTY_FORM, batch.PLAN_NO_BLOCK32, batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32,
+                  batch.PLAN_NO_HELPER):
         plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
@@ -549,7 +551,7 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
         if flags == batch.PLAN_EXACT_QUOTIENT:
             assert cheap_declined == 0
             continue
-        if flags == batch.PLAN_DEFAULT:
+        if flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_HELPER):
             print(f"fixture: {declined} declined + {unpacked} unpacked, {misses} speculation misses, {cheap_declined} "
                   f"cheap-quotient declines of {2 * ((n + 19) // 20)} slices")
             # the cheap-quotient form must carry real music: a scalefactor-0 candidate's quotient wraps to the opposite sign
