@@ -43,9 +43,13 @@ def main():
     # bench.py's valu_issue roofline reads it from here, tied to the same source hash as the traffic
     enc = d["encode"]
     if "SQ_INSTS_VALU" in enc and "SQ_WAVES" in enc:
-        res["encode"]["valu_per_slice"] = {"cheap_quotient": enc["SQ_INSTS_VALU"] / (enc["SQ_WAVES"] * 256 * 256)}
-        if "SQ_WAIT_ANY" in enc and "SQ_WAVE_CYCLES" in enc:
-            res["encode"]["sq_wait_any_frac"] = enc["SQ_WAIT_ANY"] / enc["SQ_WAVE_CYCLES"]
+        # per COMPUTE wavefront (config 3: 2048 chains, 4 per wavefront); SQ_WAVES also counts the helper wavefronts of the
+        # launch, whose few instructions are part of what a slice costs
+        compute_waves = 2048 // 4
+        res["encode"]["valu_per_slice"] = {"cheap_quotient": enc["SQ_INSTS_VALU"] / (compute_waves * 256 * 256)}
+        res["encode"]["wavefronts_launched"] = int(enc["SQ_WAVES"])
+        if "SQ_WAIT_ANY" in enc and "SQ_WAVE_CYCLES" in enc and enc["SQ_WAVES"] == compute_waves:
+            res["encode"]["sq_wait_any_frac"] = enc["SQ_WAIT_ANY"] / enc["SQ_WAVE_CYCLES"]   # (meaningless with helpers at barriers)
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
