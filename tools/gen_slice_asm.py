@@ -836,6 +836,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {CANDC}",          # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
         f"ds_read_b128 {SLOT2}, {ADDR} offset:16",
+    ] + ["s_nop 0"] * sum(int(t[4:]) for t in LAB if t.startswith("nops")) + [   # (lab: is the winner's state read exposed?)
         f"v_cmp_eq_u32 vcc, {ADDR}, {CANDC}",
         f"v_cndmask_b32 {OADDR}, %[dummy], {OCUR}, vcc",      # the winner stages its slice, the others hit a dummy
         f"v_cndmask_b32 {THR}, {LQ}, {WQr}, vcc",
