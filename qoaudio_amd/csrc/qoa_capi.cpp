@@ -103,8 +103,11 @@ static inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32)
 static int pick_cpw(size_t n_chains, uint32_t flags) {
     int forced = (int)((flags >> 4) & 7u);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    if (n_chains >= 2048) return 4;
-    if (n_chains >= 1024) return 2;
+    // As few chains per wavefront as keep the compute wavefronts at or below half of the chip's 1024 SIMDs: up to there every
+    // compute wavefront gets a helper wavefront (qoa_kernels.hip: kHelperMaxWaves), and chains that share a wavefront wait for
+    // each other's slow stretches.  Beyond 2048 chains 4 per wavefront (all 64 lanes busy).
+    if (n_chains > 1024) return 4;
+    if (n_chains > 512) return 2;
     return 1;
 }
 

@@ -18,6 +18,7 @@ enc = gpu.encoded_size(ch, samples)
 clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
 kinds = (os.environ.get("QOA_CLASSES") or "music,white,silence,loud").split(",")
 only_default = os.environ.get("QOA_DEFAULT_ONLY") == "1"
+extra = int(os.environ.get("QOA_EXTRA_FLAGS", "0"))  # e.g. batch.PLAN_FORCE_HELPER = 8192, PLAN_NO_HELPER = 4096
 for kind in kinds:
     if kind == "fixture":  # clips cut from the decoded reference fixture at offsets spread over the whole song
         import numpy as np
@@ -44,7 +45,7 @@ for kind in kinds:
     for name, fl in ((("default", 0),) if only_default else
                      (("default", 0), ("no penalty form", batch.PLAN_NO_PENALTY_FORM), ("exact quotient", batch.PLAN_EXACT_QUOTIENT),
                       ("no speculation", batch.PLAN_NO_SPECULATION))):
-        plan = batch.EncodePlan(clips, fl | batch.PLAN_COUNTERS)
+        plan = batch.EncodePlan(clips, fl | extra | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm.view(-1), out)
         torch.cuda.synchronize()
