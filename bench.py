@@ -90,7 +90,8 @@ def valu_issue(plan, samples: int, kernel_ms: float):
     achieved = per_slice * slices * waves / (kernel_ms * 1e-3) if per_slice else None
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s",
             "frac": achieved / peak if achieved else None, "wavefronts": waves, "chains_per_wavefront": cpw,
-            "step_form": form, "valu_per_slice": per_slice}
+            "step_form": form, "valu_per_slice": per_slice,
+            "helper_wavefronts": waves <= 512}  # launches of up to 512 compute wavefronts pair each with a helper
 
 
 def cpu_baseline_child(pcm_host: np.ndarray, rate: int, budget_s: float):
