@@ -19,10 +19,13 @@
 // state reaches all 16 lanes through the chain's LDS slots (ds_bpermute on the per-slice fall-back paths).
 //
 // All arithmetic reproduces the reference's 32-bit wrapping integers exactly.  The kernel is bound by VALU
-// instruction ISSUE (one wave per SIMD, ~4 cycles per instruction whatever it is), so everything is about the
-// instruction count of the serial slice step: 35 instructions on i16-packed weights/history where that is provably
-// exact (the normal case), 41 on 32-bit weights otherwise; 16 full slices at a time run inside one generated asm
-// loop (qoa_slice_asm.inc, tools/gen_slice_asm.py).  See DESIGN.md section 4.
+// instruction ISSUE (one wave per SIMD, ~4 cycles per instruction whatever it is; a branch costs 20-27), so everything is
+// about the instruction count of the serial slice step -- 22 instructions in the cheap-quotient speculative form that
+// ordinary audio runs on, 26 / 27 / 35 in the exact-quotient / penalty / full forms on i16-packed weights and history where
+// those are provably exact, 41 on 32-bit weights otherwise -- and about keeping everything else off the compute
+// wavefront: 16 full slices at a time run inside one generated asm loop with one branch per slice (qoa_slice_asm.inc,
+// tools/gen_slice_asm.py), and launches that leave SIMDs idle give every compute wavefront a helper wavefront that does
+// the memory work of the block top.  See DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -296,15 +299,17 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
 // was zero at every step, hence its rank is its true rank while every other candidate's true rank is >= its computed
 // one, and the reference's winner is this winner.  Margins for the three unsampled steps are folded into limq / winq
 // (spec_limits).  The rank is a saturating 32-bit sum (tools/gen_slice_asm.py: spec_rank_pair): a third test demands
-// that the winner's is below 32767^2, where it is provably the true rank.  A slice that fails a test ends the call
-// (done < n) with its entry state restored; the caller runs it through the full form.  `pp` = byte distance between the
-// two candidate-slot buffers.
+// that the winner's is below 32767^2, where it is provably the true rank.  All tests are folded into ONE per-lane
+// comparison at the end of the slice (tools/gen_slice_asm.py: pk_block_spec -- a lone wavefront pays 20-27 cycles per
+// branch); a slice that fails it ends the call (done < n) with its entry state restored -- the candidate slots are
+// double-buffered, `pp` = byte distance between the two buffers -- and the caller runs it through the next form down.
 //
 // CHEAP selects QOA_BLOCK_CHEAP_ASM_TEXT, the same loop with the cheap quotient (tools/gen_slice_asm.py: cheap_quotient_note):
 // 22 / 25 instructions per step.  The quantiser's level is taken from |n| and its sign from the residual, which is what the
 // reference computes unless the wrapped quotient n and the residual have opposite signs (scalefactors 0 and 1 only); such a
-// candidate is marked, leaves the election, and the winner's rank must stay below the bound that comes with the slice's
-// samples (tile record dword 0: what a marked candidate provably costs) -- else the slice is declined like a speculation miss.
+// candidate is marked and takes part in the election with the rank it provably costs at least, less one (tile record
+// dword 0, marked_bound()): if that wins -- the best unmarked rank is not below the bound -- the slice is declined like a
+// speculation miss.
 template <bool CHEAP>
 __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
                                                    int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk,
@@ -515,10 +520,10 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
 // K1: encode
 //
 // Memory schedule.  All global-memory traffic of a chain happens once per BLOCK of 16 slices
-// (320 sample-times), in straight-line code at the block top: lane j of the chain's 16-lane row
-// loads the 20 samples of slice 16*(blk+1)+j for the NEXT block (20 x 16-bit loads into 10 pair registers,
-// addresses clamped instead of branched), parks the 10 pairs it loaded one block earlier -- behind the
-// slice's marked-candidate bound, a 48-byte record -- in a wave-private LDS tile [chain][slice j]
+// (320 sample-times), in straight-line code at the block top (run by the helper wavefront of a HELPER workgroup, by the
+// compute wavefront itself otherwise): lane j of the chain's 16-lane row loads the 20 samples of slice 16*(blk+1)+j for
+// the NEXT block (20 x 16-bit loads off one address with immediate offsets), parks the 10 pairs it loaded one block
+// earlier -- behind the slice's marked-candidate bound, a 48-byte record -- in a wave-private LDS tile [chain][slice j]
 // (3 x ds_write_b128), and stores the 8-byte slice it kept for row 16*(blk-1)+j of the PREVIOUS block.
 // Inside a block there is no vector-memory instruction at all, so no s_waitcnt vmcnt can land on the
 // serial slice step; the 16 candidate lanes of a chain fetch a slice's record with 3 broadcast
