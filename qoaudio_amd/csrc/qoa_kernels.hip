@@ -307,8 +307,8 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
 // CHEAP selects QOA_BLOCK_CHEAP_ASM_TEXT, the same loop with the cheap quotient (tools/gen_slice_asm.py: cheap_quotient_note):
 // 22 / 25 instructions per step.  The quantiser's level is taken from |n| and its sign from the residual, which is what the
 // reference computes unless the wrapped quotient n and the residual have opposite signs (scalefactors 0 and 1 only); such a
-// candidate is marked and takes part in the election with the rank it provably costs at least, less one (tile record
-// dword 0, marked_bound()): if that wins -- the best unmarked rank is not below the bound -- the slice is declined like a
+// candidate is marked and takes part in the election with the rank it provably costs at least (tile record dword 0,
+// marked_bound(); real ranks count from 1 there): if that wins -- the best unmarked rank is not below the bound -- the slice is declined like a
 // speculation miss.
 template <bool CHEAP>
 __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
@@ -588,8 +588,8 @@ __device__ __forceinline__ void load_partial_slice(const int16_t *__restrict__ p
 
 // What a candidate of the slice costs at least if its quotient wraps to the opposite sign (cheap-quotient form, see
 // run_block_spec): at that step |residual| >= 32768 and |dequantised| <= 49, so |error| >= min(32719, 32767 - max|sample|).
-// Returns the square less one (at least 0): the rank a marked candidate takes into the election, so that it wins -- and the
-// slice is abandoned -- exactly when the best unmarked rank is not below the bound (pk_block_spec in the generator).
+// Returns the square: the rank a marked candidate takes into the election (where real ranks count from 1), so that it wins --
+// and the slice is abandoned -- exactly when the best unmarked rank is not below the bound (pk_block_spec in the generator).
 __device__ __forceinline__ unsigned marked_bound(const unsigned (&pairs)[10]) {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     s16x2 mx = __builtin_bit_cast(s16x2, pairs[0]), mn = mx;
@@ -602,7 +602,7 @@ __device__ __forceinline__ unsigned marked_bound(const unsigned (&pairs)[10]) {
     const int hi = max((int)mx.x, (int)mx.y), lo = min((int)mn.x, (int)mn.y);
     const int smax = max(hi, -lo);
     const int lb = max(min(32719, 32767 - smax), 0);
-    return (unsigned)max(lb * lb, 1) - 1u; // the rank a marked candidate takes into the election: its bound, less one (pk_block_spec)
+    return (unsigned)(lb * lb);
 }
 
 // the slice at `src` (tile layout: bound, unused, 10 pairs) widened to 20 ints

@@ -185,3 +185,34 @@ def test_fuzz_block_loop_from_hostile_states(gpu, oracle, seed):
         want, _ = ref.encode_frame(x)
         assert fl == n and data == want, (trial, kind, state.tolist())
         assert np.array_equal(enc.lms_state(), np.array([h + w for h, w in ref.lms_state()], dtype=np.int32))
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_marked_candidates_in_rank_ties(gpu, oracle, seed):
+    """Signals that sit on a rail, entered with predictions far beyond it: many candidates reach the SAME total rank (often
+    0: the reconstruction clamps onto the sample whatever the quantiser says), the scalefactor-0 candidate's quotient wraps
+    (it is marked in the cheap-quotient form) and the slice's sample bound is 0 -- the case in which a marked candidate and an
+    unmarked one tie and only the reference's (first-sample rank, scalefactor) order decides.  Found by the long fuzz run
+    (QOA_FUZZ_SCALE=8, seed 11, trial 391) against round 3's first branch-free marking, which let the unmarked one win."""
+    from test_gpu_parity import _oracle_with_state
+    r = np.random.default_rng(seed)
+    channels, n = 2, 640
+    for trial in range(150 * SCALE):
+        state = np.zeros((channels, 8), dtype=np.int32)
+        rail = int(r.choice([-32768, 32767]))
+        for c in range(channels):
+            amp = int(r.choice([3000, 9000, 12288, 16300]))
+            w = np.abs(r.integers(-amp, amp + 1, 4)) * (1 if r.random() < 0.7 else -1)
+            h = np.full(4, rail if r.random() < 0.7 else -rail - 1) if r.random() < 0.8 else r.integers(-32768, 32768, 4)
+            state[c] = list(h) + list(w)
+        x = np.full(n * channels, rail, dtype=np.int16)
+        if r.random() < 0.5:   # a few samples off the rail: bounds of 1, 4, 9 ...
+            idx = r.integers(0, x.size, 12)
+            x[idx] = np.clip(x[idx].astype(np.int32) - np.sign(rail) * r.integers(0, 4, 12), -32768, 32767).astype(np.int16)
+        enc = gpu.QoaEncoder(gpu.QoaDesc(channels, 44100, n))
+        enc.set_lms_state(state)
+        fl, data = enc.encode_frame(x)
+        ref = _oracle_with_state(oracle, channels, 44100, n, state)
+        want, _ = ref.encode_frame(x)
+        assert fl == n and data == want, (trial, state.tolist())
+        assert np.array_equal(enc.lms_state(), np.array([h + w for h, w in ref.lms_state()], dtype=np.int32))

@@ -343,7 +343,9 @@ def spec_rank_pair(i, N, B, E):
     that value is exact and any other is at least that large (pk_block tests the winner's)."""
     elo = N["e"].split(":")[0].replace("v[", "v")
     return (f"v_pk_sub_i16 {E}, v{SPK0 + i // 2 - 1}, {B} clamp" + N.get("fill", ""),
-            f"v_dot2_i32_i16 {elo}, {E}, {E}, {'0' if i == 2 else elo} clamp" + N.get("fill", ""))
+            # the cheap forms count the rank from 1: a marked candidate's key (its bound, see pk_block_spec) then lies strictly
+            # below its true rank + 1, and a bound of 0 beats every unmarked candidate
+            f"v_dot2_i32_i16 {elo}, {E}, {E}, {('1' if N.get('cheap') else '0') if i == 2 else elo} clamp" + N.get("fill", ""))
 
 
 def spec_aerr0(N, E, X):
@@ -724,8 +726,10 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
              replaced by "always" when the row's best rank M is not provably exact (M >= 32767^2, spec_rank_pair)
         WQ   %[winq]: the winner's penalty was not provably zero (not in the penalty form);
              replaced by "always" in a MARKED lane (cheap quotient, cheap_quotient_note): a marked candidate stays in the
-             election with rank BKEY = max(bound, 1) - 1, bound being what it provably costs at least (tile dword 0), so it
-             wins exactly when the best unmarked rank is not below the bound -- or ties with BKEY, which declines too.
+             election with its BOUND as rank -- what it provably costs at least (tile dword 0) -- while every real rank of
+             the cheap forms is counted from 1 (spec_rank_pair): the key is strictly below the candidate's true rank + 1, so an
+             unmarked winner has truly beaten it (rank + 1 <= bound <= its rank, no tie possible), and a bound of 0 -- no
+             proof at all -- wins every election, which abandons the slice.
     "always" is INT_MIN for the signed energy comparison and 0 for the unsigned penalty comparison (CH_BIG).
     The loop branch is taken when no lane's comparison fired and slices are left: tmp = fired ? -1 : done; tmp < n."""
     K1, M, K2, ADDR, OADDR, TCUR, OCUR = G["K1"], G["M"], G["K2"], G["ADDR"], G["OADDR"], G["TCUR"], G["OCUR"]
@@ -740,7 +744,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
     cmp_ge = "v_cmp_ge_u32" if pen else "v_cmp_ge_i32"
     L = [
         "s_mov_b32 s95, 0x10001",
-        f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW:x}",
+        f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW + (1 if cheap else 0):x}",   # (the cheap forms' ranks are offset by 1)
         f"v_mov_b32 {CH_BIG}, {'0' if pen else '0x80000000'}",
     ] + ([f"v_mov_b32 {MK}, 0"] if cheap else []) + [
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an exit restores
@@ -803,7 +807,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
         f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
     ] + ([
-        f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc",       # a marked candidate's rank: what it provably costs, less one
+        f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc",       # a marked candidate's rank: what it provably costs (real ranks count from 1)
         f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc",   # ... and if that wins, the slice is abandoned
         f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc",            # (diagnostics: marked (candidate, slice) pairs of this call)
     ] if cheap else [
