@@ -216,3 +216,40 @@ def test_marked_candidates_in_rank_ties(gpu, oracle, seed):
         want, _ = ref.encode_frame(x)
         assert fl == n and data == want, (trial, state.tolist())
         assert np.array_equal(enc.lms_state(), np.array([h + w for h, w in ref.lms_state()], dtype=np.int32))
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_fuzz_frames_from_hostile_states(gpu, oracle, seed):
+    """Like test_fuzz_block_loop_from_hostile_states but three whole frames per trial through the frame-at-a-time encoder: 48
+    blocks from a hostile state, so the ladder's cool-downs, the steady-state dispatch and the hand-over of the LMS state
+    between calls (device memory, full i32) all take part -- bytes of every frame and the final state against the oracle."""
+    from test_gpu_parity import _oracle_with_state
+    r = np.random.default_rng(seed)
+    channels = 2
+    for trial in range(6 * SCALE):
+        n = 5120 * 3 - int(r.integers(0, 2)) * int(r.integers(1, 5000))     # sometimes a short last frame
+        amp = int(r.choice([3000, 12288, 16300, 30000]))
+        state = np.zeros((channels, 8), dtype=np.int32)
+        for c in range(channels):
+            w = r.integers(-amp, amp + 1, 4)
+            if r.random() < 0.5:
+                w = np.abs(w) * np.sign(r.integers(0, 2) * 2 - 1)
+            h = r.integers(-32768, 32768, 4)
+            state[c] = list(h) + list(w)
+        kind = str(r.choice(["rail", "loud", "white", "mix", "square", "clipped"]))
+        if kind == "rail":
+            x = np.full(n * channels, int(r.choice([-32768, 32767])), dtype=np.int16)
+            x[r.integers(0, x.size, 40)] = r.integers(-32768, 32768, 40).astype(np.int16)
+        elif kind == "clipped":
+            x = np.clip(rng_pcm(int(r.integers(1 << 30)), n * channels, "mix").astype(np.int32) * 5, -32768, 32767).astype(np.int16)
+        else:
+            x = rng_pcm(int(r.integers(1 << 30)), n * channels, kind)
+        enc = gpu.QoaEncoder(gpu.QoaDesc(channels, 44100, n))
+        enc.set_lms_state(state)
+        ref = _oracle_with_state(oracle, channels, 44100, n, state)
+        for f0 in range(0, n, 5120):
+            piece = x[f0 * channels:min(f0 + 5120, n) * channels]
+            fl, data = enc.encode_frame(piece)
+            want, _ = ref.encode_frame(piece)
+            assert fl == len(piece) // channels and data == want, (trial, kind, f0, state.tolist())
+        assert np.array_equal(enc.lms_state(), np.array([h + w for h, w in ref.lms_state()], dtype=np.int32))
