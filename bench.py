@@ -473,6 +473,14 @@ def main():
         torch.cuda.synchronize()
         extras["config3_at_2_chains_per_wavefront_kernel_ms"] = e0.elapsed_time(e1)
         del p2
+        p3 = batch.EncodePlan(clips, batch.PLAN_NO_HELPER)  # the classic kernel: every wavefront does its own block tops
+        p3.run(pcm, out, stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); p3.run(pcm, out, stream); e1.record(stream)
+        torch.cuda.synchronize()
+        extras["config3_without_helper_wavefronts_kernel_ms"] = e0.elapsed_time(e1)
+        del p3
         plan.run(pcm, out, stream)  # `out` again holds the default plan's bytes (identical by construction; decode leg reads it)
         fc_clips, fc_frames = 8 * n_clips, max(1, args.frames // 8)
         fc_samples = fc_frames * 5120
