@@ -1041,3 +1041,19 @@ def test_many_small_workgroups_helper_and_classic(gpu, oracle, flags):
     out2 = torch.zeros_like(out)
     batch.EncodePlan(clips, fl).run(pcm, out2)
     assert torch.equal(out, out2)
+
+
+def test_plan_packing_keeps_helper_wavefronts_available(gpu):
+    """qoa_encode_plan_launch_info: up to 2048 chains a plan packs 1, 2 or 4 chains per wavefront so that it launches at
+    most 512 compute wavefronts (each then gets a helper wavefront); beyond that 4 per wavefront; the
+    QOA_PLAN_CPW_* flags override."""
+    from qoaudio_amd import batch
+    for n_clips, ch, want_cpw in ((1, 2, 1), (256, 2, 1), (257, 2, 2), (512, 2, 2), (513, 2, 4), (1024, 2, 4), (1025, 2, 4),
+                                  (1024, 1, 2), (512, 1, 1), (300, 8, 4)):
+        clips = [(i * 40 * ch, i * gpu.encoded_size(ch, 40), gpu.QoaDesc(ch, 44100, 40)) for i in range(n_clips)]
+        waves, cpw, lds = batch.EncodePlan(clips).launch_info()
+        chains = n_clips * ch
+        assert cpw == want_cpw and waves == (chains + cpw - 1) // cpw and lds == 0, (n_clips, ch, waves, cpw)
+        assert chains > 2048 or waves <= 512
+    clips = [(i * 80, i * gpu.encoded_size(2, 40), gpu.QoaDesc(2, 44100, 40)) for i in range(64)]
+    assert batch.EncodePlan(clips, batch.PLAN_CPW_4).launch_info()[:2] == (32, 4)
