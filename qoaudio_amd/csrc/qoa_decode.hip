@@ -479,6 +479,11 @@ struct K2uCfg {
 #else
     static constexpr int NSLOT = 1;
 #endif
+#ifdef QOA_K2U_FLUSH_PRIO // (tools/k2lab)
+    static constexpr int FLUSH_PRIO = QOA_K2U_FLUSH_PRIO;
+#else
+    static constexpr int FLUSH_PRIO = NCH == 8 ? 0 : 3;   // issue priority while a wavefront flushes its lines (see the flush)
+#endif
     // waves per block (multiples of 4 only: other counts load the four SIMDs unevenly -- profiles/r02_k2lab_log.md, run 20)
     static constexpr int WPB = 4;
     // vector-memory operations younger than unit n's loads at the top of unit n (steady state): the loads of the NSLOT - 1
@@ -686,6 +691,12 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 typedef unsigned u4_piece __attribute__((ext_vector_type(4), aligned(16), may_alias));
                 typedef unsigned u32_alias __attribute__((may_alias));
                 asm volatile("" ::: "memory"); // the image was written as int16: keep the dword reads below behind those stores
+                // The flushing wavefront issues ahead of the SIMD's other wavefronts (s_setprio): its LDS reads and line stores go
+                // out as one burst instead of being interleaved with the others' row arithmetic.  Measured in ONE process on the
+                // SAME buffers (tools/k2lab/ab_inproc.py -- the kernel's time depends on where its buffers lie, see
+                // profiles/r03_k2lab_log.md): stereo 1.53-1.59 -> 1.44-1.45 ms in the slow placements, 1.39-1.40 -> 1.38 in
+                // the fast ones; 1 / 4 channels -1 %; 8 channels +-2 % (left alone).  Priority for the slice loads undoes it.
+                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO);
                 static_for<0, NLS>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
                     u4_unaligned v[l1 - l0 > 0 ? l1 - l0 : 1];
@@ -706,6 +717,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     }
                 });
                 asm volatile("" ::: "memory");
+                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(0);
             }
         });
 #pragma unroll
