@@ -695,7 +695,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 // out as one burst instead of being interleaved with the others' row arithmetic.  Measured in ONE process on the
                 // SAME buffers (tools/k2lab/ab_inproc.py -- the kernel's time depends on where its buffers lie, see
                 // profiles/r03_k2lab_log.md): stereo 1.53-1.59 -> 1.44-1.45 ms in the slow placements, 1.39-1.40 -> 1.38 in
-                // the fast ones; 1 / 4 channels -1 %; 8 channels +-2 % (left alone).  Priority for the slice loads undoes it.
+                // the fast ones; 1 / 4 channels -1 %; 8 channels +-2 % (left alone).  It is the STORES that want it (priority for the
+                // flush's LDS reads alone does nothing); priority for the slice loads as well undoes it.
                 if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO);
                 static_for<0, NLS>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;

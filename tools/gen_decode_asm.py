@@ -183,7 +183,7 @@ def emit(name, lines):
 
 
 # (channels, rows per round, image ring bytes): must agree with K2uCfg in qoa_decode.hip (static_asserts there)
-GEOMETRY = {1: (16, 256), 2: (8, 256), 4: (4, 640), 8: (2, 640)}
+GEOMETRY = {1: (16, 256), 2: (8, int(os.environ.get("QOA_DEC_RING2", "256"))), 4: (4, 640), 8: (2, 640)}   # (env: tools/k2lab variants)
 
 
 def render():
@@ -207,9 +207,11 @@ INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaud
 
 def main():
     out, n = render()
-    with open(INC_PATH, "w") as f:
+    path = os.environ.get("QOA_GEN_OUT", INC_PATH)
+    assert path != INC_PATH or "QOA_DEC_RING2" not in os.environ, "lab geometry must not overwrite the product's rows"
+    with open(path, "w") as f:
         f.write(out)
-    print(f"wrote {INC_PATH}: {n} lines per row")
+    print(f"wrote {path}: {n} lines per row")
 
 
 if __name__ == "__main__":
