@@ -665,6 +665,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     if (grp >= (unsigned)CPW) return; // lanes beyond the packed chains idle
     const unsigned wave_in_block = threadIdx.x >> 6;
     const bool is_helper = HELPER && wave_in_block == 1;    // (both wavefronts of a HELPER workgroup serve the same chains)
+    // should a compute wavefront ever share its SIMD with somebody's helper, it issues first
+    if (HELPER && !is_helper) __builtin_amdgcn_s_setprio(3);
     const unsigned slot = HELPER ? 0u : wave_in_block;      // the LDS slot set of this wavefront's chains
     const unsigned wave = HELPER ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const unsigned chain_id = wave * CPW + grp;
