@@ -456,7 +456,9 @@ def main():
                                          "kernel": "qoa_decode_uniform_kernel" if ch in (1, 2, 4, 8) else "qoa_decode_frames_kernel",
                                          "algorithmic_bytes_per_launch": d_bytes},
                             "header_mismatches": dplan.mismatches(),
-                            "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt())}
+                            "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt()),
+                            "note": "this kernel's time depends on where its buffers lie (the same launch: +-5 % between "
+                                    "allocations, DESIGN.md K2u item 6)"}
         if dec_traffic_note:
             result["decode"]["roofline"]["traffic_note"] = dec_traffic_note
 
