@@ -155,3 +155,32 @@ def test_decode_kernels_do_not_spill(kernels):
     for name, ins in kernels.items():
         for i in ins:
             assert not i.startswith(("scratch_", "buffer_store", "buffer_load")), (name, i)
+
+
+def test_k2u_flush_stores_issue_at_raised_priority(kernels):
+    """K2u's line stores (1 / 2 / 4 channels) go out with the wavefront's issue priority raised (s_setprio 3 ... s_setprio 0:
+    DESIGN.md K2u item 6) -- hipcc must not have moved the stores out of that window or dropped the pair."""
+    seen = 0
+    for name, ins in kernels.items():
+        if "qoa_decode_uniform_kernel" not in name:
+            continue
+        m = re.search(r"qoa_decode_uniform_kernelILi(\d+)ELi(\d+)E", name)
+        nch = int(m.group(1))
+        prio, raised_stores, plain_stores = 0, 0, 0
+        for i in ins:
+            op = i.split()[0]
+            if op == "s_setprio":
+                prio = int(i.split()[1])
+            elif op.startswith(("s_cbranch", "s_branch")) and prio:
+                prio = prio  # (the window is straight-line code; a branch inside it would show up as plain stores below)
+            elif op == "global_store_dwordx4" and " nt" in i:
+                if prio:
+                    raised_stores += 1
+                else:
+                    plain_stores += 1
+        if nch == 8:
+            assert raised_stores == 0, name
+        else:
+            assert raised_stores > 0 and plain_stores == 0, (name, raised_stores, plain_stores)
+            seen += 1
+    assert seen >= 3
