@@ -82,7 +82,7 @@ def valu_issue(plan, samples: int, kernel_ms: float):
     most one instruction per 4 cycles whatever the wavefront count, profiles/r02_ubench_gfx950_issue_classes.txt).  The
     instruction count per slice is PMC-measured for the step form the plan's launch takes (qoa_encode_plan_launch_info);
     when the committed profile does not cover it `achieved` and `frac` are null."""
-    waves, cpw, lds = plan.launch_info()
+    waves, cpw, lds, helper = plan.launch_shape()
     form = "lds_table" if lds else "cheap_quotient"
     per_slice = pmc_valu_per_slice(form)
     slices = (samples + 19) // 20
@@ -91,7 +91,7 @@ def valu_issue(plan, samples: int, kernel_ms: float):
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s",
             "frac": achieved / peak if achieved else None, "wavefronts": waves, "chains_per_wavefront": cpw,
             "step_form": form, "valu_per_slice": per_slice,
-            "helper_wavefronts": waves <= 512}  # launches of up to 512 compute wavefronts pair each with a helper
+            "helper_wavefronts": helper}  # as the plan reports it (launches of up to 512 compute wavefronts)
 
 
 def cpu_baseline_child(pcm_host: np.ndarray, rate: int, budget_s: float):

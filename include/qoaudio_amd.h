@@ -141,7 +141,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_FORCE_HELPER 8192u     /* debug: helper wavefronts whatever the launch size */
 #define QOA_PLAN_COUNTERS 512u         /* count the fast paths' fall-backs (qoa_encode_plan_stats / _counters); without it the */
                                        /* kernel is handed no counter block and executes no atomic at all */
-#define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: chosen from batch size) */
+#define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: 4) */
 #define QOA_PLAN_CPW_2 (2u << 4)
 #define QOA_PLAN_CPW_4 (4u << 4)
 
@@ -151,11 +151,12 @@ void qoa_encode_plan_free(qoa_encode_plan *plan);
 /* Bytes the batch reads / writes (algorithmic bytes of one run). */
 int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint64_t *out_bytes,
                           uint64_t *samples_i16);
-/* How the plan's launches are shaped (diagnostics for bench.py): total wavefronts over its launches, chains per wavefront
- * of the largest launch, and whether that launch takes the LDS-table step form (chosen from 8 wavefronts per SIMD up, or
- * forced by QOA_PLAN_LDS_TABLES).  Any pointer may be null. */
+/* How the plan's launches are shaped (diagnostics for bench.py): total compute wavefronts over its launches, chains per
+ * wavefront of the largest launch, whether that launch takes the LDS-table step form (chosen from 8 wavefronts per SIMD up,
+ * or forced by QOA_PLAN_LDS_TABLES), and whether it runs two-wavefront workgroups (a helper wavefront beside every compute
+ * wavefront: launches of up to 512 compute wavefronts).  Any pointer may be null. */
 int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
-                                uint32_t *lds_table_form);
+                                uint32_t *lds_table_form, uint32_t *helper_wavefronts);
 /* Enqueue the encode of the whole batch on `stream` (a hipStream_t, may be NULL).  d_pcm and
  * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
 int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);

@@ -113,7 +113,8 @@ def lib():
     L.qoa_encode_plan_free.restype = None
     L.qoa_encode_plan_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_run.argtypes = [vp, vp, vp, vp]
-    L.qoa_encode_plan_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.qoa_encode_plan_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_uint32)]
     L.qoa_encode_plan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_counters.argtypes = [vp, C.POINTER(C.c_uint64), sz]
     L.qoa_encode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]

@@ -82,9 +82,13 @@ class EncodePlan:
 
     def launch_info(self) -> Tuple[int, int, bool]:
         """(wavefronts over all launches, chains per wavefront of the largest launch, LDS-table step form?)."""
-        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-        _lib.lib().qoa_encode_plan_launch_info(self._h, C.byref(a), C.byref(b), C.byref(c))
-        return a.value, b.value, bool(c.value)
+        return self.launch_shape()[:3]
+
+    def launch_shape(self) -> Tuple[int, int, bool, bool]:
+        """launch_info() + whether the largest launch runs helper wavefronts (qoa_encode_plan_launch_info)."""
+        a, b, c, d = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _lib.lib().qoa_encode_plan_launch_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return a.value, b.value, bool(c.value), bool(d.value)
 
     def stats(self) -> Tuple[int, int, int]:
         """(declined, unpacked, speculation_misses): slices the kernel's fast paths handed to a slower form, summed over

@@ -94,21 +94,23 @@ static inline uint32_t be32(const uint8_t *p) {
 }
 static inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
 
-// Chains-per-wavefront heuristic.  Measured on MI355X (profiles/r01a_kernel_stats.md): the kernel is
-// integer-VALU-issue bound and a gfx950 SIMD issues these integer ops at one wave-instruction per
-// ~4 cycles whether one or two wavefronts are resident, so throughput = 1 / (wave-instructions per
-// SIMD).  Packing 4 chains into each wavefront (all 64 lanes busy) is therefore never slower than
-// spreading them out, and is 1.8x faster once there are more wavefronts than SIMDs (1024).  Small
-// batches use fewer chains per wavefront only to keep ragged clips from idling their wave-mates.
+// Chains per wavefront: 4 (all 64 lanes busy), whatever the launch size.  The kernel is integer-VALU-issue bound and a
+// gfx950 SIMD issues these integer ops at one wave-instruction per ~4 cycles whether one or two wavefronts are resident, so
+// throughput = 1 / (wave-instructions per SIMD): 4 chains per wavefront is 1.8x faster than 1 once there are more wavefronts
+// than SIMDs.  Below that, round 3 spread the chains out (1 per wavefront up to 512 chains, 2 up to 1024) so that chains would
+// not wait for their wave-mates' slow stretches -- and shipped a 2x regression: a HELPER workgroup (qoa_kernels.hip) whose two
+// wavefronts have only 16 or 32 live lanes issues 15-38 % slower than the same code with 64, varying from compute unit to
+// compute unit and launch to launch (not with the data: eight identical chains spread 2333-3231 cycles per slice), and from 512
+// such workgroups up half of the compute wavefronts also share a SIMD with another workgroup's helper (2,050 ns per slice
+// against 1,000).  Measured on MI355X over 1 .. 1024 chains x 1 / 2 / 3 / 5 / 8 channels (tools/k1lab/small_launch.py,
+// profiles/r04_k1lab_log.md): 4 chains per wavefront with helper wavefronts is the fastest packing at EVERY size
+// (976-1005 ns per slice; 1 or 2 per wavefront with helpers 1090-2070, without 990-1065).  Clips are handed out longest
+// first, so the chains that share a wavefront are of similar length.  QOA_PLAN_CPW_1/2/4 force a packing (tests, lab).
 static int pick_cpw(size_t n_chains, uint32_t flags) {
+    (void)n_chains;
     int forced = (int)((flags >> 4) & 7u);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    // As few chains per wavefront as keep the compute wavefronts at or below half of the chip's 1024 SIMDs: up to there every
-    // compute wavefront gets a helper wavefront (qoa_kernels.hip: kHelperMaxWaves), and chains that share a wavefront wait for
-    // each other's slow stretches.  Beyond 2048 chains 4 per wavefront (all 64 lanes busy).
-    if (n_chains > 1024) return 4;
-    if (n_chains > 512) return 2;
-    return 1;
+    return 4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -139,7 +141,9 @@ struct EncGroup {
     DevBuf lms;
 };
 
-#ifdef QOA_LAB_STAMPS
+#if defined(QOA_LAB_HWID)
+constexpr size_t kCounters = 8 + 4096 + 2048; // + one placement record per wavefront, cycles per compute wavefront (tools/k1lab/small_launch.py)
+#elif defined(QOA_LAB_STAMPS)
 constexpr size_t kCounters = 17; // + the timing experiment's (tools/k1lab/stamps.sh)
 #else
 constexpr size_t kCounters = 8; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
@@ -243,18 +247,29 @@ static bool plan_lds_form(uint32_t flags, const EncGroup *g) {
     return !(flags & QOA_PLAN_NO_LDS_TABLES) && (g->n + g->cpw - 1) / g->cpw >= 8192u;
 }
 
+static unsigned plan_kernel_flags(uint32_t pf) {
+    return ((pf & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) | ((pf & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) |
+           ((pf & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) | ((pf & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u) |
+           ((pf & QOA_PLAN_NO_PENALTY_FORM) ? 64u : 0u) | ((pf & QOA_PLAN_NO_BLOCK32) ? 128u : 0u) |
+           ((pf & QOA_PLAN_NO_HELPER) ? 256u : 0u) | ((pf & QOA_PLAN_FORCE_HELPER) ? 512u : 0u);
+}
+
 extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
-                                           uint32_t *lds_table_form) {
+                                           uint32_t *lds_table_form, uint32_t *helper_wavefronts) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
-    uint32_t waves = 0, cpw = 0, lds = 0, biggest = 0;
+    uint32_t waves = 0, cpw = 0, lds = 0, helper = 0, biggest = 0;
     for (auto *g : plan->groups) {
         const uint32_t w = (g->n + g->cpw - 1) / g->cpw;
         waves += w;
-        if (w > biggest) { biggest = w; cpw = (uint32_t)g->cpw; lds = plan_lds_form(plan->flags, g) ? 1u : 0u; }
+        if (w > biggest) {
+            biggest = w; cpw = (uint32_t)g->cpw; lds = plan_lds_form(plan->flags, g) ? 1u : 0u;
+            helper = encode_launch_has_helper(g->cpw, g->n, plan_kernel_flags(plan->flags)) ? 1u : 0u;
+        }
     }
     if (wavefronts) *wavefronts = waves;
     if (chains_per_wavefront) *chains_per_wavefront = cpw;
     if (lds_table_form) *lds_table_form = lds;
+    if (helper_wavefronts) *helper_wavefronts = helper;
     return QOA_OK;
 }
 
@@ -264,11 +279,7 @@ extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t
 // bit8 no helper wavefronts, bit9 helper wavefronts whatever the launch size
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
-    unsigned kflags = 2u | ((plan->flags & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) |
-                      ((plan->flags & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) | ((plan->flags & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) |
-                      ((plan->flags & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u) | ((plan->flags & QOA_PLAN_NO_PENALTY_FORM) ? 64u : 0u) |
-                      ((plan->flags & QOA_PLAN_NO_BLOCK32) ? 128u : 0u) | ((plan->flags & QOA_PLAN_NO_HELPER) ? 256u : 0u) |
-                      ((plan->flags & QOA_PLAN_FORCE_HELPER) ? 512u : 0u);
+    const unsigned kflags = 2u | plan_kernel_flags(plan->flags);
     for (auto *g : plan->groups) {
         const unsigned lds = plan_lds_form(plan->flags, g) ? 16u : 0u;
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
@@ -607,7 +618,7 @@ static int encoder_run(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint3
     HIP_TRY(hipMemcpyAsync(enc->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice, enc->stream),
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(enc->pcm.p, pcm, n_i16 * 2, hipMemcpyHostToDevice, enc->stream), QOA_ENCODE_IO_ERROR);
-    HIP_TRY(launch_encode(1, enc->desc.channels, (const int16_t *)enc->pcm.p, (uint8_t *)enc->out.p,
+    HIP_TRY(launch_encode(pick_cpw(v.size(), 0), enc->desc.channels, (const int16_t *)enc->pcm.p, (uint8_t *)enc->out.p,
                           (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u, nullptr,
                           enc->stream),
             QOA_ENCODE_IO_ERROR);

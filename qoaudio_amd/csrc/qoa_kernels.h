@@ -13,6 +13,7 @@ namespace qoa {
 //       bit4: speculative steps with the quantiser / dequantiser in an LDS table (fewer issue slots, one LDS round trip per
 //             step: for launches with several wavefronts per SIMD)
 //       bit5: no cheap-quotient speculative steps (run_block_spec<true>)
+//       bit6: no penalty form   bit7: no 32-bit block statement   bit8: no helper wavefronts   bit9: helper wavefronts always
 // d_stats (may be null, 5 x u64; [3] += slices the cheap-quotient form declined, re-evaluated by the exact speculative form,
 //                        [4] += (wavefront, slice) pairs in which the cheap-quotient form marked a candidate): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
 //                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible,
@@ -20,6 +21,10 @@ namespace qoa {
 hipError_t launch_encode(int cpw, int nch, const int16_t *d_pcm, uint8_t *d_out, const EncChain *d_chains,
                          unsigned n_chains, int32_t *d_lms, unsigned flags, unsigned long long *d_stats,
                          hipStream_t stream);
+
+// Does launch_encode give this launch helper wavefronts (two-wavefront HELPER workgroups)?  flags as above (bit8 never,
+// bit9 always); the one place that decides it -- qoa_encode_plan_launch_info reports it from here.
+bool encode_launch_has_helper(int cpw, unsigned n_chains, unsigned flags);
 
 hipError_t launch_decode(const uint8_t *d_in, int16_t *d_out, const DecChain *d_chains, unsigned n_chains,
                          unsigned *d_mismatches, hipStream_t stream);

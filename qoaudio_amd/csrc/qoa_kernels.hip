@@ -671,6 +671,15 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const unsigned wave = HELPER ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const unsigned chain_id = wave * CPW + grp;
     if (chain_id >= n_chains) return;
+#ifdef QOA_LAB_HWID // placement experiment (tools/k1lab/small_launch.py): where did this wavefront land?
+    if (stats && lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        const unsigned w = wave * 2u + (is_helper ? 1u : 0u);
+        if (w < 4096u) stats[8 + w] = ((unsigned long long)(xcc & 15u) << 32) | hwid | (1ull << 63);
+    }
+    const unsigned long long hwid_t0 = __builtin_readcyclecounter();
+#endif
     const int sf = (int)(lane & 15u);
     const unsigned row_base = lane & ~15u;
     // HELPER: tiles are double-buffered (block b uses buffer b & 1; the second buffer is the slot set of "wavefront 1")
@@ -819,6 +828,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 h[4] = st.w0; h[5] = st.w1; h[6] = st.w2; h[7] = st.w3;
             }
             pair_barrier();
+            QOA_LAB_MARK(3) // (lab) [3] loop back edge + the wait at the pair barrier
             tile = tile_buf[blk & 1u];
             out_tile = out_buf[blk & 1u];
             outb_addr = (unsigned)(size_t)(lds_ptr)out_tile;
@@ -1023,6 +1033,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     } else {
         flush_block(out_tile, nblocks - 1); // the last (possibly partial) block
     }
+#ifdef QOA_LAB_HWID
+    if (stats && lane == 0 && wave < 2048u) stats[8 + 4096 + wave] = __builtin_readcyclecounter() - hwid_t0;
+#endif
     if (packed) pk_unpack(pk, st);
     if (sf == 0) {
         int32_t *s = lms_state + (size_t)chain_id * 8;
@@ -1103,6 +1116,13 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
+bool encode_launch_has_helper(int cpw, unsigned n, unsigned flags) {
+    // A launch that leaves at least half of the chip's 1024 SIMDs idle gives every compute wavefront a helper wavefront
+    // (HELPER workgroups: see the kernel).  flags bit 8: never, bit 9: always (tests, experiments).
+    const unsigned waves = (n + (unsigned)cpw - 1) / (unsigned)cpw;
+    return (flags & 256u) == 0 && (waves <= kHelperMaxWaves || (flags & 512u) != 0);
+}
+
 template <int CPW>
 static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
                                     int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream) {
@@ -1112,11 +1132,8 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
     // now 150-200).  From 4 wavefronts up the 4-wave workgroups stay: 8 single-wave workgroups on 8 CUs made the 8-channel
     // streaming call slower (0.48 vs 0.38 ms).
     unsigned waves = (n + CPW - 1) / CPW;
-    // A launch that leaves at least half of the chip's 1024 SIMDs idle gives every compute wavefront a helper wavefront
-    // (HELPER workgroups: see the kernel).  flags bit 8: never, bit 9: always (tests, experiments).
     {
-        const bool helper = (flags & 256u) == 0 && (waves <= kHelperMaxWaves || (flags & 512u) != 0);
-        if (helper) {
+        if (encode_launch_has_helper(CPW, n, flags)) {
             dim3 g(waves), b(128);
 #define QOA_LAUNCH(N)                                                                                                    \
     case N:                                                                                                              \

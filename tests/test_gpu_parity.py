@@ -1044,16 +1044,20 @@ def test_many_small_workgroups_helper_and_classic(gpu, oracle, flags):
 
 
 def test_plan_packing_keeps_helper_wavefronts_available(gpu):
-    """qoa_encode_plan_launch_info: up to 2048 chains a plan packs 1, 2 or 4 chains per wavefront so that it launches at
-    most 512 compute wavefronts (each then gets a helper wavefront); beyond that 4 per wavefront; the
-    QOA_PLAN_CPW_* flags override."""
+    """qoa_encode_plan_launch_info: a plan packs 4 chains per wavefront at every size (round 3's 1 / 2 per wavefront for small
+    launches ran up to 2x slower with helper wavefronts: tools/k1lab/small_launch.py); launches of up to 512 compute wavefronts
+    (2048 chains) report helper wavefronts, larger ones and QOA_PLAN_NO_HELPER plans do not; the QOA_PLAN_CPW_* flags
+    override the packing."""
     from qoaudio_amd import batch
-    for n_clips, ch, want_cpw in ((1, 2, 1), (256, 2, 1), (257, 2, 2), (512, 2, 2), (513, 2, 4), (1024, 2, 4), (1025, 2, 4),
-                                  (1024, 1, 2), (512, 1, 1), (300, 8, 4)):
+    for n_clips, ch in ((1, 2), (256, 2), (257, 2), (512, 2), (513, 2), (1024, 2), (1025, 2), (1024, 1), (512, 1), (300, 8), (1, 1)):
         clips = [(i * 40 * ch, i * gpu.encoded_size(ch, 40), gpu.QoaDesc(ch, 44100, 40)) for i in range(n_clips)]
-        waves, cpw, lds = batch.EncodePlan(clips).launch_info()
+        waves, cpw, lds, helper = batch.EncodePlan(clips).launch_shape()
         chains = n_clips * ch
-        assert cpw == want_cpw and waves == (chains + cpw - 1) // cpw and lds == 0, (n_clips, ch, waves, cpw)
-        assert chains > 2048 or waves <= 512
+        assert cpw == 4 and waves == (chains + 3) // 4 and lds == 0, (n_clips, ch, waves, cpw)
+        assert helper == (waves <= 512), (n_clips, ch, waves, helper)
+        assert batch.EncodePlan(clips, batch.PLAN_NO_HELPER).launch_shape()[3] is False
+        assert batch.EncodePlan(clips, batch.PLAN_FORCE_HELPER).launch_shape()[3] is True
     clips = [(i * 80, i * gpu.encoded_size(2, 40), gpu.QoaDesc(2, 44100, 40)) for i in range(64)]
     assert batch.EncodePlan(clips, batch.PLAN_CPW_4).launch_info()[:2] == (32, 4)
+    assert batch.EncodePlan(clips, batch.PLAN_CPW_1).launch_shape() == (128, 1, False, True)
+    assert batch.EncodePlan(clips, batch.PLAN_CPW_2).launch_info()[:2] == (64, 2)

@@ -17,7 +17,7 @@ samples = frames * 5120
 pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda")
 per, enc = samples * ch, gpu.encoded_size(ch, samples)
 clips = [(i * per, i * enc, gpu.QoaDesc(ch, 44100, samples)) for i in range(n_clips)]
-plan = batch.EncodePlan(clips, batch.PLAN_COUNTERS)
+plan = batch.EncodePlan(clips, batch.PLAN_COUNTERS | int(os.environ.get("QOA_EXTRA_FLAGS", "0")))
 out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
 plan.run(pcm.view(-1), out)
 torch.cuda.synchronize()
@@ -25,7 +25,7 @@ buf = (ctypes.c_uint64 * 17)()
 lib = _lib.lib()
 lib.qoa_encode_plan_counters(plan._h, buf, 17)
 c = list(buf)
-waves = n_clips * ch // 4
+waves = plan.launch_info()[0]
 ws = waves * frames * 256
 print("counters", c[:8])
 print(f"per wave-slice: steps {c[8] / ws:.1f} cycles, rest of the slice loop {c[9] / ws:.1f}, statement {c[10] / ws:.1f}, "
