@@ -124,6 +124,147 @@ def cpu_baseline_child(pcm_host: np.ndarray, rate: int, budget_s: float):
     return res
 
 
+def timed_launches(run, stream, reps=3, warm=1):
+    """kernel ms of `reps` launches of run() on `stream`, each bracketed by its own HIP event pair, behind `warm` untimed ones"""
+    for _ in range(warm):
+        run()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); run(); e1.record(stream)
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return ms
+
+
+def small_launches(q, batch, synth, dev, stream, rate, frames=16):
+    """K1 on launches far below the headline's size -- 8, 64 and 512 chains (stereo), and ONE 8-channel clip -- in ns per
+    slice (kernel time / slices per chain).  Round 3 shipped a 2x regression for launches of <= 512 chains that no record in
+    the bench line could see; this one does (default plan, as any caller gets it)."""
+    from oracle import oracle as O
+    samples = frames * 5120
+    res = {"workload": f"stereo clips x {frames} frames, default plan; ns per slice = kernel time / {frames * 256} slices per chain"}
+    for chains, ch in ((8, 2), (64, 2), (512, 2), (8, 8)):
+        n_clips = chains // ch
+        desc = q.QoaDesc(ch, rate, samples)
+        clips, _, per_enc = batch.uniform_clips(n_clips, desc)
+        pcm = synth.make_clips(n_clips, samples, ch, rate, device=dev, first_index=4096)
+        out = torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev)
+        plan = batch.EncodePlan(clips)
+        ms = min(timed_launches(lambda: plan.run(pcm, out, stream), stream))
+        waves, cpw, _, helper = plan.launch_shape()
+        ok = out[n_clips - 1].cpu().numpy().tobytes() == O.encode_all(pcm[n_clips - 1].cpu().numpy().reshape(-1), ch, rate, samples)
+        res[f"{chains}_chains" + ("_8ch" if ch == 8 else "")] = {
+            "kernel_ms": ms, "ns_per_slice": ms * 1e6 / (frames * 256), "wavefronts": waves, "chains_per_wavefront": cpw,
+            "helper_wavefronts": helper, "bit_exact_vs_oracle": bool(ok)}
+    return res
+
+
+def other_configs(q, batch, synth, dev, stream, pcm, rate, n_clips, frames):
+    """BASELINE.json's configs 2 and 5 for the record (not part of `value`): config 2 = the headline's clips as mono (channel
+    0), encode only; config 5 = the frame-at-a-time API on ONE 8-channel 48 kHz stream (200 calls of 5120 sample-times,
+    host pointers in, host bytes out, LMS state carried in the handle), against the oracle's one-shot bytes."""
+    from oracle import oracle as O
+    res = {}
+    samples = frames * 5120
+    mdesc = q.QoaDesc(1, rate, samples)
+    mclips, _, mper_enc = batch.uniform_clips(n_clips, mdesc)
+    mpcm = pcm[:, :, 0].contiguous().view(n_clips, samples, 1)
+    menc = torch.empty((n_clips, mper_enc), dtype=torch.uint8, device=dev)
+    mplan = batch.EncodePlan(mclips)
+    ms = float(np.mean(timed_launches(lambda: mplan.run(mpcm, menc, stream), stream, reps=2)))
+    k = n_clips // 2
+    ok = menc[k].cpu().numpy().tobytes() == O.encode_all(mpcm[k].cpu().numpy().reshape(-1), 1, rate, samples)
+    res["cfg2_mono_encode"] = {"workload": f"{n_clips} clips x 1 ch x {frames} frames, encode", "kernel_ms": ms,
+                               "ns_per_slice": ms * 1e6 / (frames * 256), "samples_per_s": mplan.samples / (ms * 1e-3),
+                               "bit_exact_vs_oracle": bool(ok)}
+    del mplan, menc, mpcm
+    ch5, rate5, calls = 8, 48000, 200
+    x = synth.make_clips(1, calls * 5120, ch5, rate5, device=dev, first_index=8192)[0].cpu().numpy().reshape(-1)
+    enc = q.QoaEncoder(q.QoaDesc(ch5, rate5, calls * 5120))
+    got = bytearray()
+    enc.write_header(got)
+    enc.encode_frame(x[:5120 * ch5])  # warm-up call on a throw-away handle state
+    enc = q.QoaEncoder(q.QoaDesc(ch5, rate5, calls * 5120))
+    t0 = time.perf_counter()
+    for f in range(calls):
+        enc.encode_frame(x[f * 5120 * ch5:(f + 1) * 5120 * ch5], got)
+    dt = time.perf_counter() - t0
+    want = O.encode_all(x, ch5, rate5, calls * 5120)
+    res["cfg5_stream"] = {"workload": f"1 stream x {ch5} ch x {rate5} Hz, {calls} encode_frame calls of 5120 sample-times "
+                                      f"(81,920 B in / 16,520 B out per call, host memory both sides)",
+                          "ms_per_call": dt / calls * 1e3, "x_realtime": calls * 5120 / rate5 / dt,
+                          "bit_exact_vs_oracle": bytes(got) == want}
+    return res
+
+
+def decode_over_placements(q, batch, dplan, enc, pcm_like, stream, pairs=4, warm=8, reps=10):
+    """The decode launch on `pairs` separately allocated (input, output) buffer pairs: K2u's time depends on where its buffers
+    lie (a stable property of the pair of allocations), so one pair reports the allocator's luck; the
+    figure to quote is the median over pairs.  Returns (per-pair mean kernel ms, the last pair's output)."""
+    per_pair, back = [], None
+    keep = []  # (all pairs stay allocated while the others are timed: they must be distinct placements)
+    for i in range(pairs):
+        e = enc if i == 0 else enc.clone()
+        b = torch.empty_like(pcm_like)
+        keep.append((e, b))
+    for e, b in keep:
+        for _ in range(warm):
+            dplan.run(e, b, stream)
+        evs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream); dplan.run(e, b, stream); e1.record(stream)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        per_pair.append(float(np.mean([a.elapsed_time(c) for a, c in evs])))
+        back = b
+    return per_pair, back
+
+
+def decode_record(dplan, per_pair, kernel, traffic=None, traffic_note=None):
+    d_bytes = dplan.in_bytes + dplan.pcm_bytes
+    med = float(np.median(per_pair))
+    rec = {"value": dplan.samples / (med * 1e-3), "unit": "samples/s", "kernel_ms_avg": med,
+           "kernel_ms_per_placement": [round(v, 4) for v in per_pair], "kernel_ms_min": min(per_pair), "kernel_ms_max": max(per_pair),
+           "roofline": {"bound": "hbm", "achieved": d_bytes / (med * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": d_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_best_placement": d_bytes / (min(per_pair) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_worst_placement": d_bytes / (max(per_pair) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic, "kernel": kernel, "algorithmic_bytes_per_launch": d_bytes},
+           "note": f"median over {len(per_pair)} separately allocated (input, output) buffer pairs, each the mean of back-to-back "
+                   "launches behind a warm-up: the same launch differs by several per cent between allocations (DESIGN.md K2u item 6)"}
+    if traffic_note:
+        rec["roofline"]["traffic_note"] = traffic_note
+    return rec
+
+
+def general_decode(q, batch, synth, dev, stream, rate):
+    """The decode launches that are not whole wavefronts of full 1 / 2 / 4 / 8-channel frames: 6 and 3 channels (682 clips x 64
+    frames: channel counts that do not divide a wavefront), and a stereo batch whose clips end in a short frame like the
+    reference's fixture (63 full frames + 3,082 sample-times)."""
+    from oracle import oracle as O
+    res = {}
+    for name, n_clips, ch, samples in (("6ch", 682, 6, 64 * 5120), ("3ch", 682, 3, 64 * 5120),
+                                       ("stereo_short_last_frame", 1024, 2, 63 * 5120 + 3082)):
+        desc = q.QoaDesc(ch, rate, samples)
+        clips, _, per_enc = batch.uniform_clips(n_clips, desc)
+        pcm = synth.make_clips(n_clips, samples, ch, rate, device=dev, first_index=12288)
+        enc = torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev)
+        batch.EncodePlan(clips).run(pcm, enc, stream)
+        dplan = batch.DecodePlan.from_clips(clips)
+        per_pair, back = decode_over_placements(q, batch, dplan, enc, pcm, stream, pairs=2, warm=6, reps=8)
+        k = n_clips - 1
+        ok = np.array_equal(back[k].cpu().numpy().reshape(-1), O.decode_all(enc[k].cpu().numpy().tobytes())[2])
+        rec = decode_record(dplan, per_pair, "qoa_decode_frames_kernel")
+        rec.update({"workload": f"{n_clips} clips x {ch} ch x {samples} sample-times, decode", "header_mismatches": dplan.mismatches(),
+                    "bit_exact_vs_oracle": bool(ok)})
+        res[name] = rec
+        del dplan, enc, pcm, back
+    return res
+
+
 def signal_classes(q, batch, synth, dev, stream, ch, rate, n_clips=256, frames=64):
     """K1 on the secondary signal classes of SURVEY 8(d) -- full-scale white noise (the CPU's worst realistic case),
     digital silence (its best), PCM cut from the decoded reference fixture (the reference's own bench input,
@@ -136,8 +277,10 @@ def signal_classes(q, batch, synth, dev, stream, ch, rate, n_clips=256, frames=6
     out = torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev)
     res = {"workload": f"{n_clips} clips x {ch} ch x {frames} frames per class"}
     fixture = os.path.join(ROOT, "tests", "golden", "julien_baker_sprained_ankle.qoa")
-    for kind in ("music", "white", "silence", "fixture"):
-        if kind == "fixture":
+    for kind in ("music", "white", "silence", "fixture", "loud"):
+        if kind == "loud":  # the music class amplified 3x into hard clipping: the worst material found (tools/k1lab/classes.py)
+            pcm = (synth.make_clips(n_clips, samples, ch, rate, device=dev).to(torch.int32) * 3).clamp_(-32768, 32767).to(torch.int16)
+        elif kind == "fixture":
             if ch != 2 or not os.path.exists(fixture):
                 continue
             fch, _, fpcm = O.decode_all(open(fixture, "rb").read())
@@ -160,14 +303,16 @@ def signal_classes(q, batch, synth, dev, stream, ch, rate, n_clips=256, frames=6
         cplan = batch.EncodePlan(clips, batch.PLAN_COUNTERS)
         cplan.run(pcm, out, stream)
         c = cplan.counters()
-        res[kind] = {"kernel_ms": float(np.mean(ms)), "samples_per_s": plan.samples / (float(np.mean(ms)) * 1e-3),
+        res[kind] = {"kernel_ms": float(np.mean(ms)), "ns_per_slice": float(np.mean(ms)) * 1e6 / (frames * 256),
+                     "samples_per_s": plan.samples / (float(np.mean(ms)) * 1e-3),
                      "bit_exact_vs_oracle": bool(ok),
                      "counters": {"declined_slices": c[0], "unpacked_slices": c[1], "speculation_misses": c[2],
                                   "cheap_quotient_declines": c[3], "cheap_quotient_marked_candidates": c[4],
+                                  "wavefront_slices_on_32bit_step": c[5], "penalty_form_declines": c[7],
                                   "slices_total": n_clips * ch * frames * 256}}
         del plan, cplan, pcm
     if "music" in res:
-        for kind in ("white", "silence", "fixture"):
+        for kind in ("white", "silence", "fixture", "loud"):
             if kind in res:
                 res[kind]["vs_music"] = res[kind]["kernel_ms"] / res["music"]["kernel_ms"]
     return res
@@ -427,40 +572,17 @@ def main():
 
     if not args.no_decode:
         dplan = batch.DecodePlan.from_clips(clips)
-        back = torch.empty_like(pcm)
-        # untimed warm-up: after the host-side pause above the clocks keep rising for ~30 launches (40 ms) of this 1.5-ms
-        # kernel (kernel_ms_runs showed the 10 launches behind an 8-launch warm-up still falling by 5 %)
-        for _ in range(24):
-            dplan.run(out, back, stream)
-        # the timed launches are enqueued back to back like the encode steps (a host sync after every launch lets the
-        # clocks sag between them: +5 % on this 1.6-ms kernel), one HIP event pair per launch
-        d_events = []
-        for _ in range(max(20, args.steps)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            dplan.run(out, back, stream)
-            e1.record(stream)
-            d_events.append((e0, e1))
-        torch.cuda.synchronize()
-        dev_ms = [a.elapsed_time(b) for a, b in d_events]
-        d_ms = float(np.mean(dev_ms))
-        d_bytes = dplan.in_bytes + dplan.pcm_bytes
+        # 4 separately allocated (input, output) pairs, each: untimed warm-up (the clocks keep rising for ~40 ms after a
+        # host-side pause), then launches enqueued back to back like the encode steps, one HIP event pair per launch
+        per_pair, back = decode_over_placements(q, batch, dplan, out, pcm, stream, pairs=4 if world == 1 else 1,
+                                                warm=24 if world > 1 else 12, reps=max(10, args.steps))
         dec_traffic, dec_traffic_note = pmc_traffic("decode", n_clips, ch, args.frames)
-        result["decode"] = {"value": dplan.samples / (d_ms * 1e-3), "unit": "samples/s", "kernel_ms_avg": d_ms,
-                            "kernel_ms_runs": [round(v, 4) for v in dev_ms],
-                            "roofline": {"bound": "hbm", "achieved": d_bytes / (d_ms * 1e-3) / 1e9,
-                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": d_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         "traffic": dec_traffic,
-                                         # K2u takes whole wavefronts of full frames at 1 / 2 / 4 / 8 channels
-                                         "kernel": "qoa_decode_uniform_kernel" if ch in (1, 2, 4, 8) else "qoa_decode_frames_kernel",
-                                         "algorithmic_bytes_per_launch": d_bytes},
-                            "header_mismatches": dplan.mismatches(),
-                            "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt()),
-                            "note": "this kernel's time depends on where its buffers lie (the same launch: +-5 % between "
-                                    "allocations, DESIGN.md K2u item 6)"}
-        if dec_traffic_note:
-            result["decode"]["roofline"]["traffic_note"] = dec_traffic_note
+        # K2u takes whole wavefronts of full frames at 1 / 2 / 4 / 8 channels
+        result["decode"] = decode_record(dplan, per_pair, "qoa_decode_uniform_kernel" if ch in (1, 2, 4, 8) else "qoa_decode_frames_kernel",
+                                         dec_traffic, dec_traffic_note)
+        result["decode"].update({"header_mismatches": dplan.mismatches(),
+                                 "round_trip_rms": float((back[:8].float() - pcm[:8].float()).pow(2).mean().sqrt())})
+        del back
 
     if rank == 0 and world == 1 and not args.no_extras and args.frames % 8 == 0:
         # K1 outside the headline shape (records for DESIGN.md, not part of `value`): the same 2048 chains at 2 chains per
@@ -509,7 +631,9 @@ def main():
         del fplan, fout
         torch.cuda.synchronize()
         extras["signal_classes"] = signal_classes(q, batch, synth, dev, stream, ch, args.rate)
+        extras["small_launch"] = small_launches(q, batch, synth, dev, stream, args.rate)
         result["k1_extras"] = extras
+        result["configs"] = other_configs(q, batch, synth, dev, stream, pcm, args.rate, n_clips, args.frames)
         if not args.no_decode:
             # K2u on config 2's shape (1024 mono clips x 256 frames): half the samples of config 3, the same launch geometry
             mdesc = q.QoaDesc(1, args.rate, samples)
@@ -518,27 +642,15 @@ def main():
             menc = torch.empty((n_clips, mper_enc), dtype=torch.uint8, device=dev)
             batch.EncodePlan(mclips).run(mpcm, menc, stream)
             mplan = batch.DecodePlan.from_clips(mclips)
-            mback = torch.empty_like(mpcm)
-            for _ in range(24):
-                mplan.run(menc, mback, stream)
-            m_events = []
-            for _ in range(max(20, args.steps)):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream); mplan.run(menc, mback, stream); e1.record(stream)
-                m_events.append((e0, e1))
-            torch.cuda.synchronize()
-            m_ms = float(np.mean([a.elapsed_time(b) for a, b in m_events]))
-            m_bytes = mplan.in_bytes + mplan.pcm_bytes
+            m_pairs, mback = decode_over_placements(q, batch, mplan, menc, mpcm, stream, pairs=4, warm=12, reps=10)
             from oracle import oracle as O
             m_ok = np.array_equal(mback[7].cpu().numpy().reshape(-1), O.decode_all(menc[7].cpu().numpy().tobytes())[2])
-            result["k2_extras"] = {"mono": {"workload": f"{n_clips} clips x 1 ch x {args.frames} frames, decode",
-                                            "kernel_ms_avg": m_ms, "samples_per_s": mplan.samples / (m_ms * 1e-3),
-                                            "roofline": {"bound": "hbm", "achieved": m_bytes / (m_ms * 1e-3) / 1e9,
-                                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                         "frac": m_bytes / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                         "algorithmic_bytes_per_launch": m_bytes},
-                                            "header_mismatches": mplan.mismatches(), "bit_exact_vs_oracle": bool(m_ok)}}
+            mono = decode_record(mplan, m_pairs, "qoa_decode_uniform_kernel")
+            mono.update({"workload": f"{n_clips} clips x 1 ch x {args.frames} frames, decode", "header_mismatches": mplan.mismatches(),
+                         "bit_exact_vs_oracle": bool(m_ok)})
+            result["k2_extras"] = {"mono": mono}
             del mplan, mback, menc, mpcm
+            result["k2_extras"]["general"] = general_decode(q, batch, synth, dev, stream, args.rate)
 
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

@@ -225,12 +225,22 @@ int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, const uint8_t *
  *           is being encoded (peer copies over xGMI when `out` is on the root): that IS the gather of the encoded streams.
  *   decode: `enc` is ONE source (host or root memory, out_offset counts from it), pcm[i] the destination base of shard i.
  * A shard's PCM / the output that already sits in the memory of the device that works on it is used in place (no staging
- * copy; offsets into device memory must then be 8-byte aligned for the encoded side); memory of any other device is legal
- * wherever the HIP runtime can copy from / to it.  Synchronous: complete on return.
+ * copy) when the encoded side's base and offsets are 8-byte aligned -- otherwise, and for memory of any other device
+ * (legal wherever the HIP runtime can copy from / to it), the shard goes through the pipeline's staging buffers.
+ * Stream ordering: the pipelines run on their own streams.  Before anything starts, every call waits for ALL work
+ * submitted so far to the devices it uses (hipDeviceSynchronize), so device buffers filled by earlier kernels or copies on
+ * any stream are complete when they are read or overwritten; the call is synchronous: complete on return.  The persistent
+ * handle keeps the chain / frame tables of the last batch (keyed on the clip list): repeating a batch rebuilds nothing.
  * Errors: a device ordinal that does not exist or is listed twice, and every HIP failure (peer access included), return
  * the IoError code with qoa_last_error_detail() naming the device; nothing aborts. */
 typedef struct qoa_multi qoa_multi;
 int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out);
+/* qoa_multi_create with flags.  QOA_MULTI_ALLOW_DUPLICATE_DEVICES is a TEST mode for boxes with fewer GPUs than the
+ * configuration under test: a device may be listed more than once, every entry gets its own host thread and pipeline, and
+ * every shard but the first treats the shared buffer (`out` of an encode, `enc` of a decode) as memory of a PEER device even
+ * though it is its own -- staging buffers and copies, exactly the path a second GPU takes.  Same bytes, no speed-up. */
+#define QOA_MULTI_ALLOW_DUPLICATE_DEVICES 1u
+int qoa_multi_create_flags(const int *devices, int n_devices, uint32_t flags, qoa_multi **out);
 void qoa_multi_free(qoa_multi *m);
 int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t *first, size_t *count);
 int qoa_multi_encode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const int16_t *const *pcm, uint8_t *out,

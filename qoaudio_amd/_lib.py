@@ -21,7 +21,7 @@ SYMBOLS = [
     "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_launch_info", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
     "qoa_encode_batch_host", "qoa_host_pipeline_create", "qoa_host_pipeline_free", "qoa_host_pipeline_encode",
     "qoa_host_pipeline_decode", "qoa_decode_batch_host",
-    "qoa_multi_create", "qoa_multi_free", "qoa_multi_shard", "qoa_multi_encode", "qoa_multi_decode",
+    "qoa_multi_create", "qoa_multi_create_flags", "qoa_multi_free", "qoa_multi_shard", "qoa_multi_encode", "qoa_multi_decode",
     "qoa_encode_batch_multi", "qoa_decode_batch_multi",
     "qoa_decoder_new", "qoa_decoder_new_reader", "qoa_decoder_new_streaming", "qoa_decoder_free", "qoa_decoder_mode",
     "qoa_decoder_current_frame_header", "qoa_decoder_total_duration", "qoa_decoder_next",
@@ -126,6 +126,7 @@ def lib():
     L.qoa_host_pipeline_decode.argtypes = [vp, C.POINTER(Clip), sz, vp, vp, C.c_uint32]
     ip = C.POINTER(C.c_int)
     L.qoa_multi_create.argtypes = [ip, C.c_int, C.POINTER(vp)]
+    L.qoa_multi_create_flags.argtypes = [ip, C.c_int, C.c_uint32, C.POINTER(vp)]
     L.qoa_multi_free.argtypes = [vp]
     L.qoa_multi_free.restype = None
     L.qoa_multi_shard.argtypes = [sz, C.c_int, C.c_int, szp, szp]

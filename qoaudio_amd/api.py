@@ -211,6 +211,8 @@ class QoaDecoder:
     def __init__(self, reader=None, *, _streaming=False):
         self._h = C.c_void_p(None)
         self._reader = None
+        self._owned = None        # a file this object opened itself (QoaDecoder.open): closed with the decoder
+        self._read_error = None   # what the reader raised (any exception): an I/O error of the stream, src/lib.rs:889-893
         L = _lib.lib()
         if _streaming:
             rc = L.qoa_decoder_new_streaming(C.byref(self._h))
@@ -220,11 +222,16 @@ class QoaDecoder:
             def _pull(_ctx, buf, n):  # qoa_read_fn: bytes stored, 0 at the end, negative for an I/O error
                 try:
                     chunk = reader.read(n)
-                except OSError:
+                    if chunk is None:  # a non-blocking reader with nothing to give: io::ErrorKind::WouldBlock, not the end
+                        raise BlockingIOError("reader returned None (no data available)")
+                    if len(chunk) > n:
+                        raise ValueError("reader returned more bytes than asked for")
+                except Exception as e:  # ctypes would swallow it and report 0 = a clean end of stream
+                    self._read_error = e
                     return -1
                 if not chunk:
                     return 0
-                C.memmove(buf, chunk, len(chunk))
+                C.memmove(buf, bytes(chunk), len(chunk))
                 return len(chunk)
 
             self._cb = _lib.READ_FN(_pull)  # must outlive the handle
@@ -234,8 +241,16 @@ class QoaDecoder:
             rc = L.qoa_decoder_new(buf.ctypes.data_as(C.c_void_p) if buf.size else None, buf.size, C.byref(self._h))
         if rc:
             self._h = None
-            raise DecodeError(rc)
+            raise self._error(rc)
         self._done = False
+
+    def _error(self, rc):
+        """DecodeError(rc), chained to the exception the reader raised when that is what it reports."""
+        err = DecodeError(rc)
+        cause, self._read_error = self._read_error, None
+        if cause is not None and err.kind == "IoError":
+            err.__cause__ = cause
+        return err
 
     new = classmethod(lambda cls, reader: cls(reader))
 
@@ -243,29 +258,50 @@ class QoaDecoder:
     def open(cls, path):
         """src/lib.rs:619-625"""
         try:
-            return cls(open(path, "rb"))  # io::BufReader<File>: read lazily, src/lib.rs:619-625
+            f = open(path, "rb")  # io::BufReader<File>: read lazily, src/lib.rs:619-625
         except OSError as e:
             err = DecodeError.__new__(DecodeError)
             Exception.__init__(err, f"IO error: {e}")
             err.code, err.kind = 5, "IoError"
             raise err from e
+        try:
+            dec = cls(f)
+        except BaseException:
+            f.close()
+            raise
+        dec._owned = f  # closed by close() / when the decoder is dropped; into_inner() hands it over instead
+        return dec
 
     @classmethod
     def new_streaming(cls):
         """src/lib.rs:632-638"""
         return cls(_streaming=True)
 
+    def close(self) -> None:
+        """Drop the handle; a file QoaDecoder.open() opened is closed with it."""
+        if getattr(self, "_h", None):
+            _lib.lib().qoa_decoder_free(self._h)
+            self._h = None
+        f, self._owned = getattr(self, "_owned", None), None
+        if f is not None:
+            f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
         try:  # module globals may already be torn down at interpreter exit
-            if getattr(self, "_h", None):
-                _lib.lib().qoa_decoder_free(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 
     def into_inner(self):
         """src/lib.rs:172-178: the reader, positioned behind the last frame the decoder pulled from it."""
         r, self._reader = self._reader, None
+        self._owned = None  # the caller's now
         if getattr(self, "_h", None):
             _lib.lib().qoa_decoder_free(self._h)
             self._h = None
@@ -295,7 +331,7 @@ class QoaDecoder:
             return FrameHeader(it.header.num_channels, it.header.sample_rate, it.header.num_samples_per_channel)
         if it.kind == 2:
             return None
-        raise DecodeError(it.error)
+        raise self._error(it.error)
 
     def __iter__(self) -> Iterator[QoaItem]:
         while True:
@@ -329,8 +365,20 @@ class QoaDecoder:
 
 
 def decode_all(reader) -> DecodedQoa:
-    """src/lib.rs:713-747 -- the same walk as qoa_decode_all in the C ABI, driven through the decoder
-    handle so the stream is decoded on the GPU once and drained in bulk."""
+    """src/lib.rs:713-747 -- the same walk as qoa_decode_all in the C ABI, driven through the decoder handle so the
+    stream is decoded on the GPU once and drained in bulk.  decode_all consumes its reader (`R: io::Read` by value, :713), so
+    a file-like reader is read to its end first and the whole stream goes to the GPU in one piece (the lazy, frame-at-a-time
+    pull is QoaDecoder's: one upload + launch + download per frame is the wrong shape for a bulk drain)."""
+    if hasattr(reader, "read"):
+        try:
+            reader = reader.read()
+            if reader is None:
+                raise BlockingIOError("reader returned None (no data available)")
+        except Exception as e:
+            err = DecodeError.__new__(DecodeError)
+            Exception.__init__(err, f"IO error: {e}")
+            err.code, err.kind = 5, "IoError"
+            raise err from e
     decoder = QoaDecoder(reader)
     first = decoder.next()  # :724-731: always the first FrameHeader
     assert isinstance(first, FrameHeader)

@@ -26,6 +26,7 @@ PLAN_NO_HELPER = 4096
 PLAN_FORCE_HELPER = 8192
 PLAN_COUNTERS = 512  # count the fast paths' fall-backs (EncodePlan.stats / .counters); off by default: no atomics in the kernel
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
+MULTI_ALLOW_DUPLICATE_DEVICES = 1
 
 
 def _clips_array(clips: Sequence[Tuple[int, int, QoaDesc]]):
@@ -282,11 +283,15 @@ class MultiGpu:
     clip list with its own host thread and time-sliced pipeline; with `out` on devices[0] the stage-out of every slice is
     the peer copy that gathers the encoded streams on the root (include/qoaudio_amd.h)."""
 
-    def __init__(self, devices: Sequence[int]):
+    def __init__(self, devices: Sequence[int], allow_duplicate_devices: bool = False):
+        """allow_duplicate_devices: test mode for boxes with fewer GPUs than shards (QOA_MULTI_ALLOW_DUPLICATE_DEVICES): a
+        device may be listed several times; every shard but the first then takes the staging + copy path of a peer GPU."""
         self.devices = list(devices)
         self._h = C.c_void_p(None)
+        self._marshalled = None  # (clips object, ctypes array): a repeated batch is marshalled once
         arr = (C.c_int * len(self.devices))(*self.devices)
-        rc = _lib.lib().qoa_multi_create(arr, len(self.devices), C.byref(self._h))
+        rc = _lib.lib().qoa_multi_create_flags(arr, len(self.devices), MULTI_ALLOW_DUPLICATE_DEVICES if allow_duplicate_devices else 0,
+                                               C.byref(self._h))
         if rc:
             self._h = None
             raise EncodeError(rc)
@@ -298,6 +303,14 @@ class MultiGpu:
                 self._h = None
         except Exception:
             pass
+
+    def _clips(self, clips):
+        """ctypes image of the clip list; the same list object handed in again (a loop over one batch) is not marshalled
+        again (1024 clips cost ~2 ms of Python per call otherwise)."""
+        sig = (len(clips), clips[0], clips[-1]) if len(clips) else (0,)
+        if self._marshalled is None or self._marshalled[0] is not clips or self._marshalled[2] != sig:
+            self._marshalled = (clips, _clips_array(clips), sig)
+        return self._marshalled[1]
 
     def _bases(self, tensors):
         if len(tensors) != len(self.devices):
@@ -312,7 +325,7 @@ class MultiGpu:
         out: ONE uint8 tensor for the whole batch (host, or on devices[0])."""
         if out.dtype != torch.uint8 or not out.is_contiguous():
             raise ValueError("out must be contiguous uint8")
-        arr = _clips_array(clips)
+        arr = self._clips(clips)
         rc = _lib.lib().qoa_multi_encode(self._h, arr, len(clips), self._bases(pcm), C.c_void_p(out.data_ptr()), chunk_frames)
         if rc:
             raise EncodeError(rc)
@@ -320,7 +333,7 @@ class MultiGpu:
     def decode(self, enc: torch.Tensor, clips, pcm: Sequence[torch.Tensor], chunk_frames: int = 0) -> None:
         if enc.dtype != torch.uint8 or not enc.is_contiguous():
             raise ValueError("enc must be contiguous uint8")
-        arr = _clips_array(clips)
+        arr = self._clips(clips)
         rc = _lib.lib().qoa_multi_decode(self._h, arr, len(clips), C.c_void_p(enc.data_ptr()), self._bases(pcm), chunk_frames)
         if rc:
             raise DecodeError(rc)

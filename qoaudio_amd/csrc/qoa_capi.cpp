@@ -12,6 +12,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -326,11 +328,35 @@ extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, si
 // frames [j*F, (j+1)*F) of ALL clips are one launch that still fills the chip, while the copy engines move
 // slice j+1 in and slice j-1 out.  Output bytes are identical to encode_all per clip.
 // ------------------------------------------------------------------------------------------------
+// Chain tables of a pipelined batch, kept between calls of a persistent pipeline: all time slices' tables in ONE device
+// buffer, keyed on what they were derived from (the clip list, the slice length, which sides are used in place).  A
+// repeated batch -- qoa_multi_encode on the same clip list, a bench loop -- uploads nothing and builds nothing.
+struct PipeKey {
+    std::vector<uint8_t> clips; // raw bytes of the qoa_clip array
+    uint32_t F = 0;
+    bool src_direct = false, dst_direct = false, valid = false;
+    bool matches(const qoa_clip *c, size_t n, uint32_t f, bool s, bool d) const {
+        return valid && F == f && src_direct == s && dst_direct == d && clips.size() == n * sizeof(qoa_clip) &&
+               memcmp(clips.data(), c, clips.size()) == 0;
+    }
+    void set(const qoa_clip *c, size_t n, uint32_t f, bool s, bool d) {
+        clips.assign((const uint8_t *)c, (const uint8_t *)c + n * sizeof(qoa_clip));
+        F = f; src_direct = s; dst_direct = d; valid = true;
+    }
+};
+
 struct qoa_host_pipeline {
     hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
     hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
-    DevBuf pcm[2], enc[2], chains[2], lms; // device staging, grown on demand and kept between calls
-    struct DecTablesHolder *dec = nullptr;  // decode tables (two sets), defined further down
+    DevBuf pcm[2], enc[2], lms; // device staging, grown on demand and kept between calls
+    DevBuf enc_tables;          // [time slice][chain]: EncChain tables of the batch enc_key describes
+    PipeKey enc_key, dec_key;
+    unsigned enc_group_begin[kMaxChannels + 2] = {0};
+    struct DecTablesHolder *dec = nullptr;  // decode tables (one set per time slice), defined further down
+    // qoa_multi debug mode (QOA_MULTI_ALLOW_DUPLICATE_DEVICES): treat the batch's shared buffer (`out` of an encode, `enc` of
+    // a decode) as memory of ANOTHER device even though it is this one's -- the shard then takes the staging + copy path a
+    // second GPU takes, on a box that has one
+    bool shared_side_is_remote = false;
     bool ready = false;
     hipError_t init() {
         if (ready) return hipSuccess;
@@ -370,6 +396,11 @@ static bool on_current_device(const void *p) {
     return a.type == hipMemoryTypeDevice && a.device == cur;
 }
 
+// Device memory handed to a pipeline is read / written by kernels on the pipeline's own (non-blocking) streams, which are
+// not ordered against whatever stream produced it (a memset, a generator kernel, a copy): the call first waits for
+// everything submitted to the device so far.  (Host memory is the caller's to have finished with, as for any memcpy.)
+static hipError_t order_after_device_work() { return hipDeviceSynchronize(); }
+
 static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
                             uint32_t chunk_frames) {
     if (!clips || !h_pcm || !h_out) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
@@ -382,11 +413,14 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
     }
     // qoa_multi_*: a shard whose PCM / output already sits in this device's memory is used in place (no staging copy in /
     // out); with both in place there is nothing to overlap and the batch is one launch
-    const bool src_direct = on_current_device(h_pcm), dst_direct = on_current_device(h_out);
-    if (dst_direct) { // the kernel stores 8-byte words straight into the caller's buffer
-        if ((uintptr_t)h_out % 8 != 0) return fail_msg("device output base must be 8-byte aligned", QOA_ENCODE_IO_ERROR);
-        for (size_t i = 0; i < n_clips; i++)
-            if (clips[i].out_offset % 8 != 0) return fail_msg("qoa_clip.out_offset must be 8-byte aligned", QOA_ENCODE_IO_ERROR);
+    const bool src_direct = on_current_device(h_pcm);
+    bool dst_direct = on_current_device(h_out) && !P.shared_side_is_remote;
+    const bool device_memory = src_direct || on_current_device(h_out);
+    if (dst_direct) { // the kernel would store 8-byte words straight into the caller's buffer: any odd offset sends the
+                      // batch through the staging buffers instead (as it would go for host memory)
+        if ((uintptr_t)h_out % 8 != 0) dst_direct = false;
+        for (size_t i = 0; i < n_clips && dst_direct; i++)
+            if (clips[i].out_offset % 8 != 0) dst_direct = false;
     }
     uint32_t F = chunk_frames ? chunk_frames : 8; // config 3: 102.1 ms at 8 or 4 frames, 104.9 at 16, 111.3 at 32
     if (src_direct && dst_direct) F = max_frames;
@@ -413,73 +447,92 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
               clips[1].out_offset - clips[0].out_offset >= qoa_encoded_size(clips[0].desc.channels, clips[0].desc.samples);
 
     HIP_TRY(P.init(), QOA_ENCODE_IO_ERROR);
+    if (device_memory) HIP_TRY(order_after_device_work(), QOA_ENCODE_IO_ERROR);
     PipeDrain drain{P};
     size_t n_chains_total = 0;
     for (size_t i = 0; i < n_clips; i++) n_chains_total += clips[i].desc.channels;
     for (int b = 0; b < 2; b++) {
         if (!src_direct) HIP_TRY(P.pcm[b].reserve(pcm_reg[n_clips] * 2), QOA_ENCODE_IO_ERROR);
         if (!dst_direct) HIP_TRY(P.enc[b].reserve(enc_reg[n_clips]), QOA_ENCODE_IO_ERROR);
-        HIP_TRY(P.chains[b].reserve(n_chains_total * sizeof(EncChain)), QOA_ENCODE_IO_ERROR);
     }
     HIP_TRY(P.lms.reserve(n_chains_total * 8 * sizeof(int32_t)), QOA_ENCODE_IO_ERROR);
 
     // chains are ordered by channel count (one launch per count), the order is the same in every time slice so
     // that chain ids -- and with them the carried LMS states -- are stable
-    unsigned group_begin[kMaxChannels + 2] = {0};
     std::vector<size_t> by_nch[kMaxChannels + 1];
     for (size_t i = 0; i < n_clips; i++) by_nch[clips[i].desc.channels].push_back(i);
+    auto samples_now = [&](const qoa_desc &d, uint32_t j) {
+        const uint64_t first = (uint64_t)j * F * kFrameLen;
+        return d.samples > first ? (uint32_t)std::min<uint64_t>(d.samples - first, (uint64_t)F * kFrameLen) : 0u;
+    };
 
-    std::vector<EncChain> table[2];
-    for (uint32_t j = 0; j < n_chunks + 1; j++) {
-        const int b = (int)(j & 1u);
-        if (j < n_chunks) {
-            // ---- stage in: PCM of time slice j (buffer b is free once the kernel of slice j-2 has run) ----
-            if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_in, P.k_done[b], 0), QOA_ENCODE_IO_ERROR);
-            table[b].clear();
+    // ---- chain tables of all time slices: built and uploaded once per (clip list, slice length, in-place sides) ----
+    if (!P.enc_key.matches(clips, n_clips, F, src_direct, dst_direct)) {
+        P.enc_key.valid = false;
+        std::vector<EncChain> all;
+        all.reserve((size_t)n_chunks * n_chains_total);
+        for (uint32_t j = 0; j < n_chunks; j++) {
             unsigned gb = 0;
             for (int nch = 1; nch <= kMaxChannels; nch++) {
-                group_begin[nch] = gb;
+                P.enc_group_begin[nch] = gb;
                 for (size_t i : by_nch[nch]) {
                     const qoa_desc &d = clips[i].desc;
                     const uint64_t first = (uint64_t)j * F * kFrameLen;
-                    const uint32_t now = d.samples > first ? (uint32_t)std::min<uint64_t>(d.samples - first, (uint64_t)F * kFrameLen) : 0;
                     qoa_clip c;
                     c.pcm_offset = src_direct ? clips[i].pcm_offset + first * d.channels : pcm_reg[i];
                     // in place the slice continues where the one before ended: file header + the frames so far
                     c.out_offset = !dst_direct ? enc_reg[i]
                                    : clips[i].out_offset + (j == 0 ? 0 : 8 + (uint64_t)j * F * qoa_frame_size(d.channels, kSlicesPerFrame));
                     c.desc = d;
-                    make_chains(c, j == 0, now, table[b]);
+                    make_chains(c, j == 0, samples_now(d, j), all);
                     gb += d.channels;
-                    if (now && !uniform && !src_direct)
-                        HIP_TRY(hipMemcpyAsync((int16_t *)P.pcm[b].p + pcm_reg[i], h_pcm + clips[i].pcm_offset + first * d.channels,
-                                               (size_t)now * d.channels * 2, hipMemcpyDefault, P.s_in),
-                                QOA_ENCODE_IO_ERROR);
                 }
             }
-            group_begin[kMaxChannels + 1] = gb;
-            if (uniform && !src_direct) {
-                const qoa_desc &d = clips[0].desc;
-                const uint64_t first = (uint64_t)j * F * kFrameLen;
-                const uint32_t now = (uint32_t)std::min<uint64_t>(d.samples - first, (uint64_t)F * kFrameLen);
-                HIP_TRY(hipMemcpy2DAsync(P.pcm[b].p, (pcm_reg[1] - pcm_reg[0]) * 2, h_pcm + clips[0].pcm_offset + first * d.channels,
-                                         (clips[1].pcm_offset - clips[0].pcm_offset) * 2, (size_t)now * d.channels * 2, n_clips,
-                                         hipMemcpyDefault, P.s_in),
-                        QOA_ENCODE_IO_ERROR);
+            P.enc_group_begin[kMaxChannels + 1] = gb;
+        }
+        HIP_TRY(P.enc_tables.reserve(all.size() * sizeof(EncChain)), QOA_ENCODE_IO_ERROR);
+        HIP_TRY(hipStreamSynchronize(P.s_k), QOA_ENCODE_IO_ERROR); // (no launch of an earlier call may still read the old tables)
+        HIP_TRY(hipMemcpy(P.enc_tables.p, all.data(), all.size() * sizeof(EncChain), hipMemcpyHostToDevice), QOA_ENCODE_IO_ERROR);
+        P.enc_key.set(clips, n_clips, F, src_direct, dst_direct);
+    }
+    const unsigned *group_begin = P.enc_group_begin;
+
+    for (uint32_t j = 0; j < n_chunks + 1; j++) {
+        const int b = (int)(j & 1u);
+        if (j < n_chunks) {
+            // ---- stage in: PCM of time slice j (buffer b is free once the kernel of slice j-2 has run) ----
+            if (!src_direct) {
+                if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_in, P.k_done[b], 0), QOA_ENCODE_IO_ERROR);
+                if (uniform) {
+                    const qoa_desc &d = clips[0].desc;
+                    const uint64_t first = (uint64_t)j * F * kFrameLen;
+                    HIP_TRY(hipMemcpy2DAsync(P.pcm[b].p, (pcm_reg[1] - pcm_reg[0]) * 2, h_pcm + clips[0].pcm_offset + first * d.channels,
+                                             (clips[1].pcm_offset - clips[0].pcm_offset) * 2, (size_t)samples_now(d, j) * d.channels * 2,
+                                             n_clips, hipMemcpyDefault, P.s_in),
+                            QOA_ENCODE_IO_ERROR);
+                } else {
+                    for (size_t i = 0; i < n_clips; i++) {
+                        const qoa_desc &d = clips[i].desc;
+                        const uint64_t first = (uint64_t)j * F * kFrameLen;
+                        const uint32_t now = samples_now(d, j);
+                        if (now)
+                            HIP_TRY(hipMemcpyAsync((int16_t *)P.pcm[b].p + pcm_reg[i], h_pcm + clips[i].pcm_offset + first * d.channels,
+                                                   (size_t)now * d.channels * 2, hipMemcpyDefault, P.s_in),
+                                    QOA_ENCODE_IO_ERROR);
+                    }
+                }
+                HIP_TRY(hipEventRecord(P.in_done[b], P.s_in), QOA_ENCODE_IO_ERROR);
+                HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0), QOA_ENCODE_IO_ERROR);
             }
-            HIP_TRY(hipMemcpyAsync(P.chains[b].p, table[b].data(), table[b].size() * sizeof(EncChain), hipMemcpyHostToDevice, P.s_in),
-                    QOA_ENCODE_IO_ERROR);
-            HIP_TRY(hipEventRecord(P.in_done[b], P.s_in), QOA_ENCODE_IO_ERROR);
 
             // ---- encode time slice j (its output buffer is free once slice j-2 has been copied out) ----
-            HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0), QOA_ENCODE_IO_ERROR);
-            if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0), QOA_ENCODE_IO_ERROR);
+            if (j >= 2 && !dst_direct) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0), QOA_ENCODE_IO_ERROR);
+            const EncChain *table = (const EncChain *)P.enc_tables.p + (size_t)j * n_chains_total;
             for (int nch = 1; nch <= kMaxChannels; nch++) {
-                const unsigned n = (nch < kMaxChannels ? group_begin[nch + 1] : group_begin[kMaxChannels + 1]) - group_begin[nch];
+                const unsigned n = group_begin[nch + 1 <= kMaxChannels ? nch + 1 : kMaxChannels + 1] - group_begin[nch];
                 if (!n) continue;
                 HIP_TRY(launch_encode(pick_cpw(n, 0), nch, src_direct ? h_pcm : (const int16_t *)P.pcm[b].p,
-                                      dst_direct ? h_out : (uint8_t *)P.enc[b].p,
-                                      (const EncChain *)P.chains[b].p + group_begin[nch], n,
+                                      dst_direct ? h_out : (uint8_t *)P.enc[b].p, table + group_begin[nch], n,
                                       (int32_t *)P.lms.p + (size_t)group_begin[nch] * 8, j == 0 ? 2u : 0u, nullptr, P.s_k),
                         QOA_ENCODE_IO_ERROR);
             }
@@ -500,7 +553,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                 *bytes = full * fb + (rest ? 8 + 16 * (uint64_t)d.channels + 8 * ((rest + kSliceLen - 1) / kSliceLen) * d.channels : 0);
                 *dst_off = 8 + frames_before * fb;
                 *src_off = 0;
-                if (jj == 0) { *bytes += 8; *dst_off = 0; } else { *src_off = 0; }
+                if (jj == 0) { *bytes += 8; *dst_off = 0; }
             };
             if (uniform) {
                 uint64_t dst, src, bytes;
@@ -522,8 +575,6 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
             }
             HIP_TRY(hipEventRecord(P.out_done[bo], P.s_out), QOA_ENCODE_IO_ERROR);
         }
-        // the host-side chain table of buffer b is rewritten two slices later: its upload must have happened
-        if (j < n_chunks) HIP_TRY(hipEventSynchronize(P.in_done[b]), QOA_ENCODE_IO_ERROR);
     }
     HIP_TRY(hipStreamSynchronize(P.s_out), QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipStreamSynchronize(P.s_k), QOA_ENCODE_IO_ERROR);
@@ -836,10 +887,13 @@ struct DecTables {
         for (int n = 1; n <= kMaxChannels; n++) if (n_frames[n] || n_uframes[n]) return false;
         return true;
     }
-    hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream, bool reset_mismatches = true) {
-        if (reset_mismatches) { // the count is per run (the host pipeline lets it add up over its time slices)
+    // counter: where header mismatches are counted (null: this table's own counter, reset first -- the count is per run;
+    // the host pipeline hands all its time slices one counter that adds up over the call)
+    hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream, unsigned *counter = nullptr) {
+        if (!counter) {
             hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
             if (e0 != hipSuccess) return e0;
+            counter = (unsigned *)mismatch.p;
         }
         for (int n = 1; n <= kMaxChannels; n++) {
             if (!n_uframes[n]) continue;
@@ -847,17 +901,17 @@ struct DecTables {
             // sub-buffer) the same table goes through the general kernel instead
             hipError_t e = ((uintptr_t)d_out % 16 == 0)
                                ? launch_decode_uniform(n, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n],
-                                                       (unsigned *)mismatch.p, stream)
+                                                       counter, stream)
                                : launch_decode_frames(n, true, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n],
-                                                      (unsigned *)mismatch.p, (uint8_t *)mismatch.p + 64, stream);
+                                                      counter, (uint8_t *)mismatch.p + 64, stream);
             if (e != hipSuccess) return e;
         }
         for (int n = 1; n <= kMaxChannels; n++) {
             hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
-                                                (unsigned *)mismatch.p, (uint8_t *)mismatch.p + 64, stream);
+                                                counter, (uint8_t *)mismatch.p + 64, stream);
             if (e != hipSuccess) return e;
         }
-        return launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, (unsigned *)mismatch.p, stream);
+        return launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, counter, stream);
     }
 };
 
@@ -1049,7 +1103,8 @@ extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count
 // Layout trusted like qoa_decode_plan_from_clips; every frame header is verified on the device.
 // ------------------------------------------------------------------------------------------------
 struct DecTablesHolder {
-    DecTables t[2];
+    std::vector<std::unique_ptr<DecTables>> t; // one set per time slice of the batch dec_key describes
+    DevBuf mismatch;                            // header mismatches of the whole call
 };
 
 qoa_host_pipeline::~qoa_host_pipeline() {
@@ -1077,16 +1132,19 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
         max_frames = std::max<uint32_t>(max_frames, (clips[i].desc.samples + kFrameLen - 1) / kFrameLen);
     }
     // (as in host_pipe_encode: memory of this device is used in place)
-    const bool src_direct = on_current_device(h_enc), dst_direct = on_current_device(h_pcm);
-    if (src_direct) { // the kernels read frames in place with 8-byte loads
-        if ((uintptr_t)h_enc % 8 != 0) return fail_msg("device stream base must be 8-byte aligned", QOA_DECODE_IO_ERROR);
-        for (size_t i = 0; i < n_clips; i++)
-            if (clips[i].out_offset % 8 != 0) return fail_msg("encoded offset must be 8-byte aligned", QOA_DECODE_IO_ERROR);
+    bool src_direct = on_current_device(h_enc) && !P.shared_side_is_remote;
+    const bool dst_direct = on_current_device(h_pcm);
+    const bool device_memory = dst_direct || on_current_device(h_enc);
+    if (src_direct) { // the kernels would read frames in place with 8-byte loads: odd offsets go through the staging buffers
+        if ((uintptr_t)h_enc % 8 != 0) src_direct = false;
+        for (size_t i = 0; i < n_clips && src_direct; i++)
+            if (clips[i].out_offset % 8 != 0) src_direct = false;
     }
     uint32_t F = chunk_frames ? chunk_frames : 8;
     if (src_direct && dst_direct) F = max_frames;
     const uint32_t n_chunks = (max_frames + F - 1) / F;
     HIP_TRY(P.init(), QOA_DECODE_IO_ERROR);
+    if (device_memory) HIP_TRY(order_after_device_work(), QOA_DECODE_IO_ERROR);
     PipeDrain drain{P};
     if (!P.dec) P.dec = new (std::nothrow) DecTablesHolder();
     if (!P.dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
@@ -1121,23 +1179,20 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
         *enc_off = 8 + (uint64_t)j * F * fb;
         *enc_bytes = full * fb + (rest ? qoa_frame_size(d.channels, (uint32_t)((rest + kSliceLen - 1) / kSliceLen)) : 0);
     };
-    bool first_upload[2] = {true, true};
-    std::vector<DecChain> recs;
-    for (uint32_t j = 0; j < n_chunks + 1; j++) {
-        const int b = (int)(j & 1u);
-        if (j < n_chunks) {
-            DecTables &T = P.dec->t[b];
-            // ---- stage in: encoded frames of time slice j (buffer b is free once the kernel of slice j-2 has run) ----
-            if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_in, P.k_done[b], 0), QOA_DECODE_IO_ERROR);
+
+    // ---- frame tables of all time slices: built and uploaded once per (clip list, slice length, in-place sides) ----
+    if (!P.dec_key.matches(clips, n_clips, F, src_direct, dst_direct)) {
+        P.dec_key.valid = false;
+        HIP_TRY(hipStreamSynchronize(P.s_k), QOA_DECODE_IO_ERROR); // (no launch of an earlier call may still read the old tables)
+        HIP_TRY(P.dec->mismatch.reserve(sizeof(unsigned)), QOA_DECODE_IO_ERROR);
+        P.dec->t.clear();
+        std::vector<DecChain> recs;
+        for (uint32_t j = 0; j < n_chunks; j++) {
             recs.clear();
             for (size_t i = 0; i < n_clips; i++) {
                 const qoa_desc &d = clips[i].desc;
                 uint64_t eo, eb, first, now;
                 slice_of(d, j, &eo, &eb, &first, &now);
-                if (!now) continue;
-                if (!uniform && !src_direct)
-                    HIP_TRY(hipMemcpyAsync((uint8_t *)P.enc[b].p + enc_reg[i], h_enc + clips[i].out_offset + eo, eb,
-                                           hipMemcpyDefault, P.s_in), QOA_DECODE_IO_ERROR);
                 uint64_t pos = src_direct ? clips[i].out_offset + eo : enc_reg[i];
                 uint64_t outp = dst_direct ? clips[i].pcm_offset + first * d.channels : pcm_reg[i], left = now;
                 while (left > 0) {
@@ -1153,24 +1208,46 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
                     pos += fsize; outp += (uint64_t)fl * d.channels; left -= fl;
                 }
             }
-            if (uniform && !src_direct) {
-                uint64_t eo, eb, first, now;
-                slice_of(clips[0].desc, j, &eo, &eb, &first, &now);
-                HIP_TRY(hipMemcpy2DAsync(P.enc[b].p, enc_reg[1] - enc_reg[0], h_enc + clips[0].out_offset + eo,
-                                         clips[1].out_offset - clips[0].out_offset, eb, n_clips, hipMemcpyDefault, P.s_in),
-                        QOA_DECODE_IO_ERROR);
+            std::unique_ptr<DecTables> T(new (std::nothrow) DecTables());
+            if (!T) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+            HIP_TRY(T->upload(recs, nullptr), QOA_DECODE_IO_ERROR); // (synchronous: the host copies may go)
+            P.dec->t.push_back(std::move(T));
+        }
+        P.dec_key.set(clips, n_clips, F, src_direct, dst_direct);
+    }
+    unsigned *const bad_count = (unsigned *)P.dec->mismatch.p;
+    HIP_TRY(hipMemsetAsync(bad_count, 0, sizeof(unsigned), P.s_k), QOA_DECODE_IO_ERROR);
+
+    for (uint32_t j = 0; j < n_chunks + 1; j++) {
+        const int b = (int)(j & 1u);
+        if (j < n_chunks) {
+            DecTables &T = *P.dec->t[j];
+            // ---- stage in: encoded frames of time slice j (buffer b is free once the kernel of slice j-2 has run) ----
+            if (!src_direct) {
+                if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_in, P.k_done[b], 0), QOA_DECODE_IO_ERROR);
+                if (uniform) {
+                    uint64_t eo, eb, first, now;
+                    slice_of(clips[0].desc, j, &eo, &eb, &first, &now);
+                    HIP_TRY(hipMemcpy2DAsync(P.enc[b].p, enc_reg[1] - enc_reg[0], h_enc + clips[0].out_offset + eo,
+                                             clips[1].out_offset - clips[0].out_offset, eb, n_clips, hipMemcpyDefault, P.s_in),
+                            QOA_DECODE_IO_ERROR);
+                } else {
+                    for (size_t i = 0; i < n_clips; i++) {
+                        uint64_t eo, eb, first, now;
+                        slice_of(clips[i].desc, j, &eo, &eb, &first, &now);
+                        if (now)
+                            HIP_TRY(hipMemcpyAsync((uint8_t *)P.enc[b].p + enc_reg[i], h_enc + clips[i].out_offset + eo, eb,
+                                                   hipMemcpyDefault, P.s_in), QOA_DECODE_IO_ERROR);
+                    }
+                }
+                HIP_TRY(hipEventRecord(P.in_done[b], P.s_in), QOA_DECODE_IO_ERROR);
+                HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0), QOA_DECODE_IO_ERROR);
             }
-            HIP_TRY(T.upload(recs, P.s_in, false), QOA_DECODE_IO_ERROR);
-            if (first_upload[b]) { // the mismatch counter adds up over the slices of this call
-                HIP_TRY(hipMemsetAsync(T.mismatch.p, 0, sizeof(unsigned), P.s_in), QOA_DECODE_IO_ERROR);
-                first_upload[b] = false;
-            }
-            HIP_TRY(hipEventRecord(P.in_done[b], P.s_in), QOA_DECODE_IO_ERROR);
             // ---- decode time slice j (its PCM buffer is free once slice j-2 has been copied out) ----
-            HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0), QOA_DECODE_IO_ERROR);
-            if (j >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0), QOA_DECODE_IO_ERROR);
-            HIP_TRY(T.run(src_direct ? h_enc : (const uint8_t *)P.enc[b].p, dst_direct ? h_pcm : (int16_t *)P.pcm[b].p, P.s_k, false),
-                    QOA_DECODE_IO_ERROR);
+            if (j >= 2 && !dst_direct) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0), QOA_DECODE_IO_ERROR);
+            if (!T.empty())
+                HIP_TRY(T.run(src_direct ? h_enc : (const uint8_t *)P.enc[b].p, dst_direct ? h_pcm : (int16_t *)P.pcm[b].p, P.s_k, bad_count),
+                        QOA_DECODE_IO_ERROR);
             HIP_TRY(hipEventRecord(P.k_done[b], P.s_k), QOA_DECODE_IO_ERROR);
         }
         if (j >= 1 && !dst_direct) {
@@ -1197,18 +1274,11 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
             }
             HIP_TRY(hipEventRecord(P.out_done[bo], P.s_out), QOA_DECODE_IO_ERROR);
         }
-        // the host copies of table set b are rewritten two slices later: its upload must have run by then
-        if (j < n_chunks) HIP_TRY(hipEventSynchronize(P.in_done[b]), QOA_DECODE_IO_ERROR);
     }
     HIP_TRY(hipStreamSynchronize(P.s_out), QOA_DECODE_IO_ERROR);
     HIP_TRY(hipStreamSynchronize(P.s_k), QOA_DECODE_IO_ERROR);
     uint32_t bad = 0;
-    for (int b = 0; b < 2; b++) {
-        if (first_upload[b]) continue;
-        uint32_t m = 0;
-        HIP_TRY(hipMemcpy(&m, P.dec->t[b].mismatch.p, sizeof m, hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
-        bad += m;
-    }
+    HIP_TRY(hipMemcpy(&bad, bad_count, sizeof bad, hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
     if (bad) return fail_msg("frame headers in the batch do not match the clip descriptions", QOA_DECODE_INVALID_FRAME_HEADER);
     return QOA_OK;
 }
@@ -1255,10 +1325,11 @@ struct qoa_multi {
     }
 };
 
-extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out) {
+extern "C" int qoa_multi_create_flags(const int *devices, int n_devices, uint32_t flags, qoa_multi **out) {
     if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
     *out = nullptr;
     if (!devices || n_devices < 1) return fail_msg("qoa_multi_create: empty device list", QOA_ENCODE_IO_ERROR);
+    const bool allow_dup = (flags & QOA_MULTI_ALLOW_DUPLICATE_DEVICES) != 0;
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count), QOA_ENCODE_IO_ERROR);
     for (int i = 0; i < n_devices; i++) {
@@ -1267,23 +1338,30 @@ extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **o
                        " visible)";
             return QOA_ENCODE_IO_ERROR;
         }
-        for (int k = 0; k < i; k++)
+        for (int k = 0; k < i && !allow_dup; k++)
             if (devices[k] == devices[i]) return fail_msg("qoa_multi_create: a device is listed twice", QOA_ENCODE_IO_ERROR);
     }
     int cur = 0;
     HIP_TRY(hipGetDevice(&cur), QOA_ENCODE_IO_ERROR);
-    auto *m = new (std::nothrow) qoa_multi();
-    if (!m) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
-    m->devices.assign(devices, devices + n_devices);
-    m->pipes.assign((size_t)n_devices, nullptr);
+    qoa_multi *m = nullptr;
+    try {
+        m = new qoa_multi();
+        m->devices.assign(devices, devices + n_devices);
+        m->pipes.assign((size_t)n_devices, nullptr);
+    } catch (const std::exception &) {
+        delete m;
+        return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
+    }
     int rc = QOA_OK;
     for (int i = 0; i < n_devices && rc == QOA_OK; i++) {
         hipError_t e = hipSetDevice(devices[i]);
         if (e == hipSuccess) {
             m->pipes[(size_t)i] = new (std::nothrow) qoa_host_pipeline();
             e = m->pipes[(size_t)i] ? m->pipes[(size_t)i]->init() : hipErrorOutOfMemory;
+            // debug mode: every shard but the root's treats the shared buffer as a peer's memory (staging + copies)
+            if (m->pipes[(size_t)i] && allow_dup && i > 0) m->pipes[(size_t)i]->shared_side_is_remote = true;
         }
-        if (e == hipSuccess && i > 0) { // direct stores into the root's memory where the link allows it
+        if (e == hipSuccess && i > 0 && devices[i] != devices[0]) { // direct stores into the root's memory where the link allows it
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
                 const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
@@ -1299,6 +1377,10 @@ extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **o
     return QOA_OK;
 }
 
+extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out) {
+    return qoa_multi_create_flags(devices, n_devices, 0u, out);
+}
+
 extern "C" void qoa_multi_free(qoa_multi *m) { delete m; }
 
 extern "C" int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t *first, size_t *count) {
@@ -1309,27 +1391,64 @@ extern "C" int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t 
     return QOA_OK;
 }
 
-// runs fn(i) on one host thread per device that has work, each bound to its device; first failure wins
+// runs fn(i) for every device that has work, each call bound to its device: on one host thread per device -- a single
+// working device runs on the caller's thread -- first failure wins.  Nothing may leave through the C ABI as an exception:
+// a thread that cannot be started (std::system_error) ends the call with the IoError code once the threads already
+// running have been joined.
 template <class Fn>
 static int multi_run(qoa_multi *m, size_t n_clips, int io_error, Fn fn) {
     const int n = (int)m->devices.size();
-    std::vector<int> rcs((size_t)n, QOA_OK);
-    std::vector<std::string> details((size_t)n);
-    std::vector<std::thread> threads;
-    for (int i = 0; i < n; i++) {
-        size_t first = 0, count = 0;
-        (void)qoa_multi_shard(n_clips, n, i, &first, &count);
-        if (!count) continue;
-        threads.emplace_back([&, i, first, count]() {
-            const hipError_t e = hipSetDevice(m->devices[(size_t)i]);
-            rcs[(size_t)i] = e == hipSuccess ? fn(i, first, count) : fail_hip(e, "hipSetDevice", io_error);
-            if (rcs[(size_t)i] != QOA_OK) details[(size_t)i] = "device " + std::to_string(m->devices[(size_t)i]) + ": " + g_detail;
-        });
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur), io_error);
+    struct Work { int i; size_t first, count; };
+    try {
+        std::vector<Work> work;
+        for (int i = 0; i < n; i++) {
+            size_t first = 0, count = 0;
+            (void)qoa_multi_shard(n_clips, n, i, &first, &count);
+            if (count) work.push_back({i, first, count});
+        }
+        // the shards' device memory is used in place by kernels on the pipelines' own streams: order the call after
+        // everything submitted to these devices so far (see order_after_device_work)
+        for (int i = 0; i < n; i++) {
+            bool seen = false;
+            for (int k = 0; k < i; k++) seen = seen || m->devices[(size_t)k] == m->devices[(size_t)i];
+            if (seen) continue;
+            hipError_t e = hipSetDevice(m->devices[(size_t)i]);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) { (void)hipSetDevice(cur); return fail_hip(e, "qoa_multi: device synchronize", io_error); }
+        }
+        std::vector<int> rcs(work.size(), QOA_OK);
+        std::vector<std::string> details(work.size());
+        auto body = [&](size_t k) {
+            const Work &w = work[k];
+            const hipError_t e = hipSetDevice(m->devices[(size_t)w.i]);
+            rcs[k] = e == hipSuccess ? fn(w.i, w.first, w.count) : fail_hip(e, "hipSetDevice", io_error);
+            if (rcs[k] != QOA_OK) details[k] = "device " + std::to_string(m->devices[(size_t)w.i]) + ": " + g_detail;
+        };
+        if (work.size() == 1) {
+            body(0);
+        } else {
+            std::vector<std::thread> threads;
+            bool spawn_failed = false;
+            for (size_t k = 0; k < work.size() && !spawn_failed; k++) {
+                try {
+                    threads.emplace_back(body, k);
+                } catch (const std::exception &) {
+                    spawn_failed = true;
+                }
+            }
+            for (auto &t : threads) t.join();
+            if (spawn_failed) { (void)hipSetDevice(cur); return fail_msg("qoa_multi: could not start a host thread", io_error); }
+        }
+        (void)hipSetDevice(cur);
+        for (size_t k = 0; k < work.size(); k++)
+            if (rcs[k] != QOA_OK) { g_detail = details[k]; return rcs[k]; }
+        return QOA_OK;
+    } catch (const std::exception &) {
+        (void)hipSetDevice(cur);
+        return fail_msg("qoa_multi: out of memory", io_error);
     }
-    for (auto &t : threads) t.join();
-    for (int i = 0; i < n; i++)
-        if (rcs[(size_t)i] != QOA_OK) { g_detail = details[(size_t)i]; return rcs[(size_t)i]; }
-    return QOA_OK;
 }
 
 extern "C" int qoa_multi_encode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const int16_t *const *pcm, uint8_t *out,

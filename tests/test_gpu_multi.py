@@ -175,3 +175,100 @@ def test_abi_multi_two_devices(gpu, oracle):
     he = out.cpu().numpy()
     for k, (po, oo, dd) in enumerate(clips):
         assert he[oo:oo + per_enc].tobytes() == oracle.encode_all(host[po:po + per_pcm], 2, 44100, d.samples)
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_abi_multi_duplicate_devices_vs_oracle(gpu, oracle, where, n_shards):
+    """qoa_multi_* with n_devices >= 2 on a ONE-GPU box: QOA_MULTI_ALLOW_DUPLICATE_DEVICES lists device 0 several times, so
+    the per-device host threads, the shard offsets relative to pcm[i], and -- for every shard but the first -- the staging
+    buffers and copies into a shared buffer that is treated as a peer's (the NON-LOCAL `out` / `enc` path of a second GPU)
+    all execute: ragged and uniform batches, device and host memory, every clip against the oracle, twice (the second call
+    runs on the handle's cached chain / frame tables) and once more with other data in the same layout."""
+    from qoaudio_amd import batch
+    m = batch.MultiGpu([0] * n_shards, allow_duplicate_devices=True)
+    dev = "cuda:0" if where == "device" else "cpu"
+    for uniform in (False, True):
+        if uniform:
+            d = gpu.QoaDesc(2, 44100, 5 * 5120 + 333)
+            clips, per_pcm, per_enc = batch.uniform_clips(13, d)
+            n_enc = 13 * per_enc
+        else:
+            clips, _, n_enc = _ragged_batch(gpu)
+        n = len(clips)
+        shard_of, base = [], []
+        for i in range(n_shards):
+            first, count = batch.multi_shard(n, n_shards, i)
+            shard_of += [i] * count
+            base.append(clips[first][0] if count else 0)
+        rel = [(po - base[shard_of[k]], oo, dd) for k, (po, oo, dd) in enumerate(clips)]  # offsets count from the shard's base
+        n_pcm = clips[-1][0] + clips[-1][2].samples * clips[-1][2].channels
+        for seed in (31 + uniform, 31 + uniform, 90):
+            host = rng_pcm(seed, n_pcm, "mix")
+            shards = []
+            for i in range(n_shards):
+                first, count = batch.multi_shard(n, n_shards, i)
+                end = clips[first + count - 1][0] + clips[first + count - 1][2].samples * clips[first + count - 1][2].channels if count else 0
+                shards.append(torch.from_numpy(host[base[i]:end].copy() if count else np.zeros(1, np.int16)).to(dev))
+            out = torch.zeros(n_enc, dtype=torch.uint8, device=dev)
+            m.encode(shards, rel, out, chunk_frames=2)
+            he = out.cpu().numpy()
+            for po, oo, d in clips:
+                want = oracle.encode_all(host[po:po + d.samples * d.channels], d.channels, d.sample_rate, d.samples)
+                assert he[oo:oo + len(want)].tobytes() == want
+            backs = [torch.zeros_like(t) for t in shards]
+            m.decode(out, rel, backs, chunk_frames=2)
+            for k, (po, oo, d) in enumerate(rel):
+                _, _, want = oracle.decode_all(he[oo:oo + gpu.encoded_size(d.channels, d.samples)].tobytes())
+                assert np.array_equal(backs[shard_of[k]].cpu().numpy()[po:po + d.samples * d.channels], want)
+
+
+def test_abi_multi_orders_itself_after_the_producer_stream(gpu, oracle):
+    """Device buffers handed to qoa_multi_encode straight from the kernels that fill them (no synchronize in between, a
+    side stream): the call waits for the device's outstanding work before its own streams read PCM or overwrite `out`
+    (advisor finding, round 3: the in-place path ran unordered against the producer)."""
+    from qoaudio_amd import batch
+    d = gpu.QoaDesc(2, 44100, 3 * 5120)
+    clips, per_pcm, per_enc = batch.uniform_clips(64, d)
+    host = rng_pcm(11, 64 * per_pcm, "mix")
+    src = torch.from_numpy(host).pin_memory()
+    m = batch.MultiGpu([0])
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            big = torch.empty(64 << 20, dtype=torch.int16, device="cuda:0")
+            for _ in range(8):
+                big.add_(1)                                     # keeps the side stream busy ahead of the producer
+            pcm = torch.empty(64 * per_pcm, dtype=torch.int16, device="cuda:0")
+            pcm.copy_(src, non_blocking=True)
+            pcm.add_(0)
+            out = torch.empty(64 * per_enc, dtype=torch.uint8, device="cuda:0")
+            out.fill_(0xEE)                                     # lands AFTER the encode if the call does not order itself
+        m.encode([pcm], clips, out)
+        he = out.cpu().numpy()
+        for k in (0, 31, 63):
+            po, oo, _ = clips[k]
+            assert he[oo:oo + per_enc].tobytes() == oracle.encode_all(host[po:po + per_pcm], 2, 44100, d.samples)
+
+
+def test_abi_multi_unaligned_device_output_takes_the_staging_path(gpu, oracle):
+    """An encoded buffer in device memory whose base is not 8-byte aligned is accepted like the same layout in host memory
+    (round 3 returned IoError for it): the shard goes through the staging buffers."""
+    from qoaudio_amd import batch
+    d = gpu.QoaDesc(2, 44100, 2 * 5120 + 40)
+    clips, per_pcm, per_enc = batch.uniform_clips(5, d)
+    host = rng_pcm(3, 5 * per_pcm, "mix")
+    pcm = torch.from_numpy(host).to("cuda:0")
+    raw = torch.zeros(5 * per_enc + 16, dtype=torch.uint8, device="cuda:0")
+    out = raw[4:4 + 5 * per_enc]                              # base % 8 == 4
+    assert out.data_ptr() % 8 == 4
+    m = batch.MultiGpu([0])
+    m.encode([pcm], clips, out)
+    he = out.cpu().numpy()
+    for po, oo, _ in clips:
+        assert he[oo:oo + per_enc].tobytes() == oracle.encode_all(host[po:po + per_pcm], 2, 44100, d.samples)
+    back = torch.zeros_like(pcm)
+    m.decode(out, clips, [back])
+    for po, oo, _ in clips:
+        _, _, want = oracle.decode_all(he[oo:oo + per_enc].tobytes())
+        assert np.array_equal(back.cpu().numpy()[po:po + per_pcm], want)

@@ -296,6 +296,70 @@ def test_lazy_reader_item_order_and_position(gpu, oracle):
     assert e.value.kind == "IoError"
 
 
+def test_reader_exceptions_are_io_errors_not_a_clean_end(gpu, oracle, tmp_path):
+    """Whatever a Python reader raises -- not only OSError -- is an I/O error of the stream (io::Error -> DecodeError::IoError,
+    src/lib.rs:889-893), never a silent truncation; read() returning None (a non-blocking reader without data) likewise.
+    QoaDecoder.open() closes its file when the constructor fails and when the decoder is closed; decode_all(reader) drains
+    the reader and decodes the stream in one piece (advisor findings, round 3)."""
+    x = rng_pcm(8, 5200 * 2)
+    enc = oracle.encode_all(x, 2, 32000, 5200)
+
+    class Raises(_ChunkReader):
+        def __init__(self, data, at, exc):
+            super().__init__(data, [512])
+            self.at, self.exc = at, exc
+
+        def read(self, n=1 << 30):
+            if self.pos >= self.at:
+                if self.exc is None:
+                    return None
+                raise self.exc
+            return super().read(min(n, self.at - self.pos))
+
+    for exc in (ValueError("I/O operation on closed file"), RuntimeError("custom reader"), None):
+        got = _items(gpu.QoaDecoder(Raises(enc, 8 + 4136, exc)), gpu)   # fails at the boundary behind the first frame
+        assert got[-1] == ("Err", "IoError") and sum(1 for k, _ in got if k == "Sample") == 5120 * 2
+        dec = gpu.QoaDecoder(Raises(enc, 8 + 4136 + 100, exc))
+        with pytest.raises(gpu.DecodeError) as e:
+            for _ in dec:
+                pass
+        assert e.value.kind == "IoError"
+        assert isinstance(e.value.__cause__, type(exc) if exc is not None else BlockingIOError)
+        with pytest.raises(gpu.DecodeError) as e:
+            gpu.QoaDecoder(Raises(enc, 5, exc))                          # inside new()
+        assert e.value.kind == "IoError" and e.value.__cause__ is not None
+        with pytest.raises(gpu.DecodeError) as e:
+            gpu.decode_all(Raises(enc, 100, exc))
+        assert e.value.kind == "IoError"
+    # open(): the file is closed when new() fails, and with the decoder
+    bad = tmp_path / "bad.qoa"
+    bad.write_bytes(b"riff" + enc[4:])
+    import gc, warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", ResourceWarning)
+        with pytest.raises(gpu.DecodeError):
+            gpu.QoaDecoder.open(str(bad))
+        gc.collect()
+    good = tmp_path / "good.qoa"
+    good.write_bytes(enc)
+    dec = gpu.QoaDecoder.open(str(good))
+    f = dec._owned
+    assert f is not None and not f.closed
+    n = sum(1 for it in dec if isinstance(it, gpu.Sample))
+    assert n == 5200 * 2
+    dec.close()
+    assert f.closed
+    dec = gpu.QoaDecoder.open(str(good))
+    f = dec.into_inner()                                                 # handed over: the caller's to close
+    assert not f.closed
+    f.close()
+    # decode_all over a file object: one drain, the same samples as over the bytes
+    with open(good, "rb") as fh:
+        d = gpu.decode_all(fh)
+        assert fh.read() == b""
+    assert d.num_channels == 2 and np.array_equal(d.samples, oracle.decode_all(enc)[2])
+
+
 def test_streaming_decoder_decode_frame(gpu, oracle, fixture_bytes):
     """src/lib.rs:1034-1066, plus sample values and a multi-frame append."""
     dec = gpu.QoaDecoder.new_streaming()
