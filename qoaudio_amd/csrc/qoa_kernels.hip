@@ -310,7 +310,7 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
 // candidate is marked and takes part in the election with the rank it provably costs at least (tile record dword 0,
 // marked_bound(); real ranks count from 1 there): if that wins -- the best unmarked rank is not below the bound -- the slice is declined like a
 // speculation miss.
-template <bool CHEAP>
+template <bool CHEAP, bool COUNT = false>
 __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
                                                    int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk,
                                                    unsigned *marked_pairs = nullptr, unsigned long long *lab = nullptr) {
@@ -331,21 +331,29 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
         [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768),       \
         [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
     if constexpr (CHEAP) {
-        register unsigned marks asm("v99"); // this lane's marked (candidate, slice) pairs of the call
 #ifdef QOA_LAB_STAMPS // timing experiment (tools/k1lab/stamps.py): cycles inside the 20 steps / in the rest of the slice loop
         unsigned tb, tt;
         asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
-                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks), [tb] "=&s"(tb), [tt] "=&s"(tt)
+                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), [tb] "=&s"(tb), [tt] "=&s"(tt)
                      : QOA_SPEC_INPUTS
-                     : QOA_SPEC_CLOBBERS, "s86", "s87", "s88", "s89", "s90", "s91", "s92");
+                     : QOA_SPEC_CLOBBERS, "v99", "s86", "s87", "s88", "s89", "s90", "s91", "s92");
         if (lab) { lab[0] += tb; lab[1] += tt; }
+        if (marked_pairs) *marked_pairs = 0;
 #else
-        asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
-                     : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks)
-                     : QOA_SPEC_INPUTS
-                     : QOA_SPEC_CLOBBERS);
+        if constexpr (COUNT) { // plans with counters: the text that also counts this lane's marked (candidate, slice) pairs
+            register unsigned marks asm("v99");
+            asm volatile(QOA_BLOCK_CHEAP_COUNT_ASM_TEXT
+                         : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks)
+                         : QOA_SPEC_INPUTS
+                         : QOA_SPEC_CLOBBERS);
+            if (marked_pairs) *marked_pairs = marks;
+        } else {
+            asm volatile(QOA_BLOCK_CHEAP_ASM_TEXT
+                         : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
+                         : QOA_SPEC_INPUTS
+                         : QOA_SPEC_CLOBBERS, "v99");
+        }
 #endif
-        if (marked_pairs) *marked_pairs = marks;
     } else {
         asm volatile(QOA_BLOCK_SPEC_ASM_TEXT
                      : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
@@ -371,19 +379,17 @@ __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned c
     register unsigned pa asm("v86") = pk.pa;
     register unsigned pb asm("v87") = pk.pb;
     unsigned done, tmp;
-    register unsigned marks asm("v99");
     asm volatile(QOA_BLOCK_PEN_ASM_TEXT
-                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp), "=v"(marks)
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
                    [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
                    [selb] "v"(k.selbase), [hi] "v"(k.hi), [limitv] "v"(kPkPenLimit), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
                    [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
                  : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
                    "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
-                   "v95", "v96", "v97", "v98", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                   "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
                    "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
                    "v124", "v125", "v126", "v127");
-    (void)marks;
     pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
     return done;
 }
@@ -868,14 +874,17 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         const unsigned tile0 = (unsigned)(size_t)(lds_int)tile, dummy_addr = outb_addr + 8u * (16u + (unsigned)sf);
         bool cheap_declined = false; // the steady path's statement has already declined slice j
         if (__builtin_amdgcn_ballot_w64(blk >= ok_blocks) == 0ull) { // steady: the whole block on the cheap-quotient statement
-            unsigned marked;
+            unsigned marked = 0;
 #ifdef QOA_LAB_STAMPS
             const unsigned long long lab_c0 = __builtin_readcyclecounter();
             j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk, &marked,
                                      lab_acc);
             lab_acc[2] += __builtin_readcyclecounter() - lab_c0;
 #else
-            j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk, &marked);
+            if (stats) // (wave-uniform: a kernel argument)
+                j = run_block_spec<true, true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk, &marked);
+            else
+                j = run_block_spec<true>(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, kBlockSlices, pk);
 #endif
             j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
             if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
@@ -898,9 +907,13 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                             const bool cheap = allow_cheap && cheap_cooldown == 0;
                             if (cheap) {
                                 if (!cheap_declined) {
-                                    unsigned marked;
-                                    j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
-                                                              dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
+                                    unsigned marked = 0;
+                                    if (stats)
+                                        j += run_block_spec<true, true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
+                                                                        dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
+                                    else
+                                        j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
+                                                                  dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk);
                                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
                                     if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
                                 }

@@ -261,7 +261,7 @@ def test_kernel_quantiser_closed_form_is_exact_for_every_residual():
 def test_cheap_quotient_form_is_exact_wherever_it_does_not_mark():
     """K1's cheap-quotient step (tools/gen_slice_asm.py: cheap_quotient_note) for EVERY residual the packed forms can see
     (|residual| <= 2^18 + 32768: i16 weights and history) and all 16 scalefactors: a1 = sgn'(v), q = n * a1 with n taken as
-    the signed high word of the 32-bit product, level = min(q, 7) & -10, code = level - (v >> 31), dequantised = mag * a1.
+    the signed high word of the 32-bit product, level = med3(q, -1, 7) & -10, code = level - (v >> 31), dequantised = mag * a1.
     Wherever q >= 0 code and dequantised value equal the reference's (src/lib.rs:613-617, :569-572); q < 0 (the lane is
     marked) happens only at scalefactors 0 and 1, only with |v| >= 32768, and -- the premise of the marked-candidate
     bound -- the reference's own dequantised value is then at most 49 in magnitude."""
@@ -280,7 +280,7 @@ def test_cheap_quotient_form_is_exact_wherever_it_does_not_mark():
         sn = res >> 31                                                  # v_ashrrev_i32 31
         a1 = sn | 1                                                     # v_or_b32 1
         q = wrap32(sext24(sext16(u >> 16)) * sext24(a1))                # v_mul_i32_i24_sdwa, src0 = sext(WORD_1)
-        t = np.minimum(q, 7)                                            # v_min_i32 (kept for the marking OR)
+        t = np.clip(q, -1, 7)                                           # v_med3_i32 q, -1, 7
         level = t & -10                                                 # v_and_b32 -10
         ok = q >= 0
         mag = DEQUANT[sf][np.where(ok, level, 0)]
@@ -288,7 +288,8 @@ def test_cheap_quotient_form_is_exact_wherever_it_does_not_mark():
         code_k = level - sn
         assert np.array_equal(code_ref[ok], code_k[ok]) and np.array_equal(deq_ref[ok], deq_k[ok]), sf
         marked = ~ok
-        assert np.array_equal(t[marked] < 0, np.ones(marked.sum(), dtype=bool))  # the OR of the steps' t sees it
+        # a marked step's "level" is 0xfffffff6: OR-ed into a slice-word half it sets bits 31..4 (test below: the sign bit stays)
+        assert np.array_equal(level[marked] & 0xffffffff, np.full(marked.sum(), 0xfffffff6))
         if sf >= 2:
             assert not marked.any(), sf
         else:
@@ -296,6 +297,35 @@ def test_cheap_quotient_form_is_exact_wherever_it_does_not_mark():
             assert np.abs(deq_ref[marked]).max() <= 49
         marked_total += int(marked.sum())
     assert marked_total > 0
+
+
+def test_cheap_quotient_mark_is_the_sign_bit_of_a_slice_word_half():
+    """The cheap forms accumulate a slice-word half as acc = (acc << 3 | level) - (v >> 31) over 10 steps from 0
+    (tools/gen_slice_asm.py: pk_step).  Unmarked steps only: the 30-bit string of codes, bits 31 and 30 clear.  A marked step
+    ORs 0xfffffff6 in; whatever the other steps do, bit 31 is then set at the end -- the mark the election reads instead of
+    round 3's v_or3 per step pair.  Every position of one marked step, random other steps, and several marked steps."""
+    r = np.random.default_rng(11)
+    for trial in range(4000):
+        n_marked = trial % 4                                            # 0, 1, 2, 3 marked steps
+        where = set(r.choice(10, n_marked, replace=False).tolist()) if n_marked else set()
+        if trial < 10:
+            where = {trial}                                             # every single position
+        acc, codes = 0, []
+        for i in range(10):
+            neg = int(r.integers(0, 2))
+            if i in where:
+                level = 0xfffffff6
+            else:
+                level = int(r.integers(0, 4)) * 2
+                codes.append(level + neg)
+            acc = (((acc << 3) & 0xffffffff) | level)                   # v_lshl_or_b32
+            acc = (acc + neg) & 0xffffffff                              # v_sub_u32 acc, acc, (v >> 31)
+        assert bool(acc >> 31) == bool(where), (trial, where, hex(acc))
+        if not where:
+            want = 0
+            for c in codes:
+                want = want << 3 | c
+            assert acc == want and acc < 1 << 30
 
 
 def test_mul24_equals_wrapping_mul_inside_the_guard():

@@ -271,11 +271,14 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         # word select, and further down dequantised = magnitude * a1.
         f"v_or_b32 {A1}, 1, {SN}",
         f"v_mul_i32_i24_sdwa {U}, sext({U}), {A1} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD",
-        f"v_min_i32 {X}, 7, {U}",                           # kept for the flag OR of the step pair
-        f"v_and_b32 {T}, -10, {X}",                         # 2 * level (0xfffffff6: a negative q stays harmlessly wide)
+        f"v_med3_i32 {T}, {U}, -1, 7",                      # clamp(q, -1, 7): a negative q -- the lane is marked -- becomes all ones
+        f"v_and_b32 {T}, -10, {T}",                         # 2 * level; marked: 0xfffffff6
     ]) + [
         f"v_mad_u32_u24 {D}, {T}, %[c101], %[selb]",
-        f"v_lshl_add_u32 {acc}, {acc}, 3, {T}",
+        # cheap forms: OR instead of add -- the same for a level, and a marked step sets bits 31..4 of the slice-word half: bit
+        # 31 then stays set through the <= 9 shifts that follow (the run of ones always reaches it), which is the MARK the
+        # election reads (round 3 OR-ed the steps' clamped quotients together: one v_or3 per step pair, 10 per slice)
+        f"v_lshl_or_b32 {acc}, {acc}, 3, {T}" if cheap else f"v_lshl_add_u32 {acc}, {acc}, 3, {T}",
         f"v_perm_b32 {D}, %[dqhi], %[dqlo], {D}",
         f"v_sub_u32 {acc}, {acc}, {SN}",
     ] + ([
@@ -311,9 +314,6 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         if i == 2:
             k = L.index(slot_b) + 1
             L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
-        if cheap and i % 2:                                  # flag OR over this step and the one before it
-            xp, xa = f"v{PK_X}", N["alt"][7]
-            L.append((f"v_or_b32 {CH_W}, {xp}, {xa}" if i == 1 else f"v_or3_b32 {CH_W}, {CH_W}, {xp}, {xa}") + N.get("fill", ""))
     return L
 
 
@@ -350,8 +350,9 @@ def spec_rank_pair(i, N, B, E):
 
 def spec_aerr0(N, E, X):
     """|err| of the first sample (orders the first-sample ranks) from the low half of the first error pair"""
-    return [l + N.get("fill", "") for l in (f"v_bfe_i32 {X}, {E}, 0, 16", f"v_sub_u32 {N['aerr0']}, 0, {X}",
-                                            f"v_max_i32 {N['aerr0']}, {X}, {N['aerr0']}")]
+    sd = "dst_sel:DWORD dst_unused:UNUSED_PAD"
+    return [l + N.get("fill", "") for l in (f"v_sub_u32_sdwa {X}, 0, sext({E}) {sd} src0_sel:DWORD src1_sel:WORD_0",
+                                            f"v_max_i32_sdwa {N['aerr0']}, sext({E}), {X} {sd} src0_sel:WORD_0 src1_sel:DWORD")]
 
 
 # Speculative block loops: the part of a candidate's end state that the next slice's first steps would otherwise re-derive
@@ -592,7 +593,7 @@ def schedule(lines):
 LAB = set(filter(None, os.environ.get("QOA_GEN_LAB", "").split(",")))   # timing experiments (tools/k1lab/stamps.sh); never in the product
 
 
-def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
+def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, count=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -635,7 +636,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
     dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
     assert ELO == ELO_REG
     if spec:
-        return pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, dict(
+        return pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, dict(
             K1=K1, M=M, K2=K2, ADDR=ADDR, OADDR=OADDR, TCUR=TCUR, OCUR=OCUR, SHI=SHI, SLO=SLO, ELO=ELO, CANDC=CANDC,
             PADDR=PADDR, THR=THR, QM=QM, reads=reads, dpp=dpp))
     # ---- the full form ----
@@ -713,7 +714,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False):
     return L
 
 
-def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
+def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
     """The speculative block loops (exact quotient, cheap quotient, LDS tables, penalty form).  ONE branch per slice:
     a not-taken s_cbranch_vccnz behind its v_cmp costs a lone wavefront ~24 cycles and a taken branch ~21
     (tools/ubench/branchbench.hip) -- the four exit tests of round 2's loop plus the loop branch were 4.6 % of the slice.
@@ -746,7 +747,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
         "s_mov_b32 s95, 0x10001",
         f"s_mov_b32 s94, 0x{RANK_EXACT_BELOW + (1 if cheap else 0):x}",   # (the cheap forms' ranks are offset by 1)
         f"v_mov_b32 {CH_BIG}, {'0' if pen else '0x80000000'}",
-    ] + ([f"v_mov_b32 {MK}, 0"] if cheap else []) + [
+    ] + ([f"v_mov_b32 {MK}, 0"] if cheap and count else []) + [
         "ds_write_b128 %[cand], v[84:87]",                   # slot = entry state: what an exit restores
         f"v_mov_b32 {TCUR}, %[tile]",
         f"v_subrev_u32 {OCUR}, 8, %[outb]",
@@ -758,7 +759,6 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
     ] + (["s_mov_b32 s90, 0", "s_mov_b32 s91, 0", "s_memtime s[88:89]"] if stamps else []) + [
         "s_waitcnt lgkmcnt(0)",
         "Lqoa_top_%=:",
-        f"v_mov_b32 {PADDR}, {ADDR}",                        # the slot that holds this slice's entry state
         # the winner's state; a slice-word store may trail, and SLOT2's read (waited for below)
         "s_waitcnt lgkmcnt(2)",
     ] + (["s_memtime s[86:87]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s86, s88", "s_add_u32 s91, s91, s92"] if stamps else []) + (
@@ -781,10 +781,12 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
     else:
         E = N["alt"][8]                                      # pair 9: the odd pairs' register (pk_step)
         body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,       # the last error pair (spec_rank_pair)
-                 f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL,
-                 f"v_xor_b32 {CANDC}, %[pp], {CANDC}" + FILL]                      # the other slot buffer: the entry state stays put
-        if cheap:
-            body.append(f"v_cmp_gt_i32 vcc, 0, {CH_W}" + FILL)                     # marked lanes (cheap_quotient_note)
+                 f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL]
+        if not cheap:                                                              # (the cheap forms switch in an election gap)
+            body.append(f"v_xor_b32 {CANDC}, %[pp], {CANDC}" + FILL)              # the other slot buffer: the entry state stays put
+        if cheap:                                                                  # marked lanes (cheap_quotient_note): the sign
+            body.append(f"v_or_b32 {CH_W}, {N['acca']}, {N['accb']}" + FILL)       # bit of a slice-word half (pk_step)
+            body.append(f"v_cmp_gt_i32 vcc, 0, {CH_W}" + FILL)
         if pen:   # total rank = err^2 sum + penalty sum (both < 2^31: no carry); scheduled, so the v_dot2 wait states hold
             body.append(f"v_add_u32 {ELO}, {ELO}, {N['pen']}")
         body, b2b = schedule(body)
@@ -806,23 +808,26 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]",      # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
         f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
-    ] + ([
-        f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc",       # a marked candidate's rank: what it provably costs (real ranks count from 1)
-        f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc",   # ... and if that wins, the slice is abandoned
-        f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc",            # (diagnostics: marked (candidate, slice) pairs of this call)
-    ] if cheap else [
-        f"v_or_b32 {SHI}, %[sfsh], {SHI}",
-    ]) + [
-        f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
-    ] + ([f"v_or_b32 {SHI}, %[sfsh], {SHI}"] if cheap else [f"v_add_u32 {OCUR}, 8, {OCUR}"]) + [
-        f"v_add_u32 {TCUR}, 48, {TCUR}",
-        dpp(M, 4),
-        reads[0],
-        reads[1],
-        dpp(M, 2),
-        reads[2],
-        f"v_add_u32 {OCUR}, 8, {OCUR}" if cheap else "s_nop 0",
-        dpp(M, 1),
+    ]
+    # First reduction: M = the row's best rank.  A DPP read needs two instructions between it and the VALU write of its
+    # source: the gaps hold the election's own bookkeeping -- slice-word head, tile / out-tile cursors, the next slice's three
+    # sample reads, the switch to the other slot buffer.
+    or_shi, add_t, add_o = f"v_or_b32 {SHI}, %[sfsh], {SHI}", f"v_add_u32 {TCUR}, 48, {TCUR}", f"v_add_u32 {OCUR}, 8, {OCUR}"
+    xor_c = f"v_xor_b32 {CANDC}, %[pp], {CANDC}"             # the other slot buffer: the entry state stays put
+    dpp8 = f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf"
+    if cheap:
+        L += [
+            f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc",   # a marked candidate's rank: what it provably costs (real ranks count from 1)
+            f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc",   # ... and if that wins, the slice is abandoned
+        ]
+        if count:                                            # (counting plans: marked (candidate, slice) pairs of this call)
+            L += [f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc", dpp8, or_shi, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2],
+                  add_o, xor_c, dpp(M, 1)]
+        else:
+            L += [or_shi, dpp8, add_t, reads[0], dpp(M, 4), reads[1], reads[2], dpp(M, 2), add_o, xor_c, dpp(M, 1)]
+    else:
+        L += [or_shi, dpp8, add_o, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2], "s_nop 0", dpp(M, 1)]
+    L += [
         f"v_cmp_eq_u32 vcc, {K1}, {M}",
         f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
         f"ds_write_b128 {CANDC}, v[84:87]",
@@ -835,7 +840,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, G):
         "s_nop 0" if ldsq else f"v_mov_b32 {N['acca']}, 0",  # the next slice's word (pk_step: acc_cleared)
         dpp(K2, 2),
         "s_nop 0" if ldsq else f"v_mov_b32 {N['accb']}, 0",
-        "s_nop 0",
+        f"v_mov_b32 {PADDR}, {ADDR}",                        # the slot that holds this slice's entry state (read if it is abandoned)
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {CANDC}",          # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
@@ -877,6 +882,7 @@ def render(verbose=False):
     blk_spec = pk_block(verbose, spec=True)
     blk_ldsq = pk_block(verbose, spec=True, ldsq=True)
     blk_cheap = pk_block(verbose, spec=True, cheap=True)
+    blk_cheap_count = pk_block(False, spec=True, cheap=True, count=True)
     blk_pen = pk_block(verbose, spec=True, cheap=True, pen=True)
     blk_32 = b32_block()
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
@@ -894,6 +900,8 @@ def render(verbose=False):
            + "// QOA_BLOCK_CHEAP_ASM_TEXT: the speculative loop with the cheap quotient (22/25 VALU per step; level from |n|, sign\n"
            + "//   from the residual, candidates whose quotient wrapped to the opposite sign are marked and proven losers).\n"
            + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap) + "\n"
+           + "// QOA_BLOCK_CHEAP_COUNT_ASM_TEXT: the same with a count of the marked (candidate, slice) pairs (plans with counters).\n"
+           + emit("QOA_BLOCK_CHEAP_COUNT_ASM_TEXT", blk_cheap_count) + "\n"
            + "// QOA_BLOCK_PEN_ASM_TEXT: the cheap-quotient loop WITH the penalty arithmetic on every step (27/step): what the\n"
            + "//   block loop falls back to where the speculative forms miss (winners that carry a penalty), before the full form.\n"
            + emit("QOA_BLOCK_PEN_ASM_TEXT", blk_pen) + "\n"
