@@ -246,18 +246,23 @@ def general_decode(q, batch, synth, dev, stream, rate):
     reference's fixture (63 full frames + 3,082 sample-times)."""
     from oracle import oracle as O
     res = {}
-    for name, n_clips, ch, samples in (("6ch", 682, 6, 64 * 5120), ("3ch", 682, 3, 64 * 5120),
-                                       ("stereo_short_last_frame", 1024, 2, 63 * 5120 + 3082)):
+    for name, n_clips, ch, samples, pad in (("6ch", 682, 6, 64 * 5120, 0), ("3ch", 682, 3, 64 * 5120, 0),
+                                            ("stereo_short_last_frame", 1024, 2, 63 * 5120 + 3082, 2),
+                                            ("stereo_short_last_frame_packed", 1024, 2, 63 * 5120 + 3082, 0)):
+        # pad: extra sample-times per clip in the PCM tensor so that every clip starts on a 16-byte boundary (325,642 stereo
+        # sample-times are 8 bytes short of one); packed = clips back to back: every second clip's PCM is 8 bytes off the
+        # grid and takes the general kernel for ALL of its frames
         desc = q.QoaDesc(ch, rate, samples)
         clips, _, per_enc = batch.uniform_clips(n_clips, desc)
-        pcm = synth.make_clips(n_clips, samples, ch, rate, device=dev, first_index=12288)
+        clips = [(k * (samples + pad) * ch, oo, dd) for k, (po, oo, dd) in enumerate(clips)]
+        pcm = synth.make_clips(n_clips, samples + pad, ch, rate, device=dev, first_index=12288)
         enc = torch.empty((n_clips, per_enc), dtype=torch.uint8, device=dev)
         batch.EncodePlan(clips).run(pcm, enc, stream)
         dplan = batch.DecodePlan.from_clips(clips)
         per_pair, back = decode_over_placements(q, batch, dplan, enc, pcm, stream, pairs=2, warm=6, reps=8)
         k = n_clips - 1
-        ok = np.array_equal(back[k].cpu().numpy().reshape(-1), O.decode_all(enc[k].cpu().numpy().tobytes())[2])
-        rec = decode_record(dplan, per_pair, "qoa_decode_frames_kernel")
+        ok = np.array_equal(back[k, :samples].cpu().numpy().reshape(-1), O.decode_all(enc[k].cpu().numpy().tobytes())[2])
+        rec = decode_record(dplan, per_pair, "qoa_decode_uniform_kernel" + (" + qoa_decode_frames_kernel" if name.startswith("stereo") else ""))
         rec.update({"workload": f"{n_clips} clips x {ch} ch x {samples} sample-times, decode", "header_mismatches": dplan.mismatches(),
                     "bit_exact_vs_oracle": bool(ok)})
         res[name] = rec

@@ -24,6 +24,7 @@ PLAN_NO_PENALTY_FORM = 1024
 PLAN_NO_BLOCK32 = 2048
 PLAN_NO_HELPER = 4096
 PLAN_FORCE_HELPER = 8192
+PLAN_NO_WIDE_FORM = 16384
 PLAN_COUNTERS = 512  # count the fast paths' fall-backs (EncodePlan.stats / .counters); off by default: no atomics in the kernel
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 MULTI_ALLOW_DUPLICATE_DEVICES = 1
@@ -103,10 +104,10 @@ class EncodePlan:
     def counters(self) -> Tuple[int, ...]:
         """stats() + (slices the cheap-quotient step form declined, (candidate, slice) pairs it marked,
         wavefront-slices on the 32-bit / tail path, wavefront-slices on the one-slice packed statement, slices the
-        penalty form declined)
+        penalty form declined, slices the wide form declined, wavefront-slices the wide form settled)
         (qoa_encode_plan_counters)."""
-        out = (C.c_uint64 * 8)()
-        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 8)
+        out = (C.c_uint64 * 10)()
+        rc = _lib.lib().qoa_encode_plan_counters(self._h, out, 10)
         if rc:
             raise EncodeError(rc)
         return tuple(int(v) for v in out)

@@ -144,11 +144,11 @@ struct EncGroup {
 };
 
 #if defined(QOA_LAB_HWID)
-constexpr size_t kCounters = 8 + 4096 + 2048; // + one placement record per wavefront, cycles per compute wavefront (tools/k1lab/small_launch.py)
+constexpr size_t kCounters = 10 + 4096 + 2048; // + one placement record per wavefront, cycles per compute wavefront (tools/k1lab/small_launch.py)
 #elif defined(QOA_LAB_STAMPS)
-constexpr size_t kCounters = 17; // + the timing experiment's (tools/k1lab/stamps.sh)
+constexpr size_t kCounters = 19; // + the timing experiment's (tools/k1lab/stamps.sh)
 #else
-constexpr size_t kCounters = 8; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
+constexpr size_t kCounters = 10; // kernel diagnostics per plan (qoa_kernels.h: d_stats)
 #endif
 struct qoa_encode_plan {
     std::vector<EncGroup *> groups;
@@ -253,7 +253,8 @@ static unsigned plan_kernel_flags(uint32_t pf) {
     return ((pf & QOA_PLAN_FORCE_GENERIC_PATH) ? 1u : 0u) | ((pf & QOA_PLAN_FORCE_32BIT_STEP) ? 4u : 0u) |
            ((pf & QOA_PLAN_NO_SPECULATION) ? 8u : 0u) | ((pf & QOA_PLAN_EXACT_QUOTIENT) ? 32u : 0u) |
            ((pf & QOA_PLAN_NO_PENALTY_FORM) ? 64u : 0u) | ((pf & QOA_PLAN_NO_BLOCK32) ? 128u : 0u) |
-           ((pf & QOA_PLAN_NO_HELPER) ? 256u : 0u) | ((pf & QOA_PLAN_FORCE_HELPER) ? 512u : 0u);
+           ((pf & QOA_PLAN_NO_HELPER) ? 256u : 0u) | ((pf & QOA_PLAN_FORCE_HELPER) ? 512u : 0u) |
+           ((pf & QOA_PLAN_NO_WIDE_FORM) ? 1024u : 0u);
 }
 
 extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
@@ -278,7 +279,7 @@ extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t
 // kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
 // bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table,
 // bit5 no cheap-quotient speculative steps, bit6 no penalty form, bit7 no 32-bit block statement,
-// bit8 no helper wavefronts, bit9 helper wavefronts whatever the launch size
+// bit8 no helper wavefronts, bit9 helper wavefronts whatever the launch size, bit10 no wide form
 extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     const unsigned kflags = 2u | plan_kernel_flags(plan->flags);
@@ -816,9 +817,21 @@ struct DecTables {
     DevBuf frames[kMaxChannels + 1];
     unsigned n_frames[kMaxChannels + 1] = {0};
     bool whole_pieces[kMaxChannels + 1] = {false};
-    // K2u (qoa_decode.hip): uniform full frames of 1 / 2 channels whose PCM sits at a multiple of 16 bytes, in whole
-    // wavefronts of 64 / channels frames; what does not fill a wavefront stays in frames[]
-    DevBuf uframes[kMaxChannels + 1]; // K2u tables: channel counts with decode_uniform_group() != 0 (1, 2, 4, 8)
+    // K2u (qoa_decode.hip): uniform full frames (256 rows, 5120 sample-times) of 1 .. 8 channels whose PCM sits at a multiple
+    // of 16 bytes; everything else stays in frames[] for the general kernel
+    DevBuf uframes[kMaxChannels + 1];
+    // The general kernel's launches (short last frames of clips, odd alignments) run BESIDE K2u's on a side stream: behind it
+    // on the same stream a few hundred short frames kept the chip for a wavefront's lifetime (0.2-0.6 ms) on their own.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DecTables() = default;
+    DecTables(const DecTables &) = delete;
+    DecTables &operator=(const DecTables &) = delete;
+    ~DecTables() {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
     unsigned n_uframes[kMaxChannels + 1] = {0};
     DevBuf chains;
     unsigned n_chains = 0;
@@ -846,13 +859,12 @@ struct DecTables {
             if (!decode_uniform_group(n)) continue;
             std::vector<DecChain> rest;
             for (const DecChain &d : per[n]) {
+                // (K2u's line stores need the 16-byte grid: tried with dword-aligned PCM in round 4 -- 128-byte runs that straddle
+                // two lines -- it ran 1.4-1.6x SLOWER than the general kernel: 2.07 vs 1.44 ms on 2048 stereo clips x 64 frames)
                 const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 16 == 0;
                 (uniform ? uni[n] : rest).push_back(d);
             }
-            const size_t group = decode_uniform_group(n), keep = uni[n].size() / group * group;
-            rest.insert(rest.end(), uni[n].begin() + keep, uni[n].end());
-            uni[n].resize(keep);
-            per[n].swap(rest);
+            per[n].swap(rest); // (K2u's last wave may be short of frames: nothing is left over for a launch of its own)
         }
         const bool fresh = mismatch.p == nullptr;
         hipError_t e = mismatch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
@@ -895,23 +907,44 @@ struct DecTables {
             if (e0 != hipSuccess) return e0;
             counter = (unsigned *)mismatch.p;
         }
+        bool has_u = false, has_g = n_chains != 0;
+        for (int n = 1; n <= kMaxChannels; n++) { has_u = has_u || n_uframes[n]; has_g = has_g || n_frames[n]; }
+        hipStream_t gs = stream; // where the general kernel's launches go
+        if (has_u && has_g) {
+            hipError_t e = hipSuccess;
+            if (!side) e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+            if (e == hipSuccess && !ev_fork) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess && !ev_join) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev_fork, stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+            if (e != hipSuccess) return e;
+            gs = side;
+        }
+        for (int n = 1; n <= kMaxChannels; n++) {
+            hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n], counter,
+                                                (uint8_t *)mismatch.p + 64, gs);
+            if (e != hipSuccess) return e;
+        }
+        {
+            hipError_t e = launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, counter, gs);
+            if (e != hipSuccess) return e;
+        }
         for (int n = 1; n <= kMaxChannels; n++) {
             if (!n_uframes[n]) continue;
             // K2u stores 16-byte pieces at frame offsets that are multiples of 16: with an odd base pointer (a caller's
             // sub-buffer) the same table goes through the general kernel instead
             hipError_t e = ((uintptr_t)d_out % 16 == 0)
-                               ? launch_decode_uniform(n, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n],
-                                                       counter, stream)
-                               : launch_decode_frames(n, true, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n],
-                                                      counter, (uint8_t *)mismatch.p + 64, stream);
+                               ? launch_decode_uniform(n, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n], counter, stream)
+                               : launch_decode_frames(n, true, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n], counter,
+                                                      (uint8_t *)mismatch.p + 64, stream);
             if (e != hipSuccess) return e;
         }
-        for (int n = 1; n <= kMaxChannels; n++) {
-            hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n],
-                                                counter, (uint8_t *)mismatch.p + 64, stream);
+        if (gs != stream) { // join: the caller's stream continues when both are done
+            hipError_t e = hipEventRecord(ev_join, side);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_join, 0);
             if (e != hipSuccess) return e;
         }
-        return launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, counter, stream);
+        return hipSuccess;
     }
 };
 

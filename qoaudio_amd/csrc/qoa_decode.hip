@@ -448,19 +448,34 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
 struct K2uCfg {
-    static constexpr int FPW = 64 / NCH;                 // frames (groups) per wave
-    static constexpr int RR = 16 / NCH;                  // rows per round: 128 B of slices, 640 B (5 lines) of PCM per frame
+    static constexpr bool POW2 = (NCH & (NCH - 1)) == 0; // 1, 2, 4, 8: the channels of a frame fill whole wavefronts
+    static constexpr int FPW = 64 / NCH;                 // frames (groups) per wave; the 64 - FPW * NCH lanes beyond them (3, 5, 6, 7
+                                                         // channels) mirror lanes of the last frame and write to a spare image
+    static constexpr int LIVE = FPW * NCH;
+    static constexpr int gcd16() { int g = 16, n = NCH; while (n) { int t = g % n; g = n; n = t; } return g; }
+    // rows per round: the fewest whose PCM is whole 128-byte lines of every frame (40 NCH bytes per row):
+    // 1 / 2 / 4 / 8 channels 16 / 8 / 4 / 2 rows = 640 B; 6 channels 8 rows = 1920 B; 3 / 5 / 7 channels 16 rows
+    static constexpr int RR = 16 / gcd16();
 #ifdef QOA_K2U_HR2
     static constexpr int HR = NCH == 2 ? QOA_K2U_HR2 : NCH == 1 ? 4 : RR;
 #else
-    static constexpr int HR = NCH == 1 ? 4 : NCH == 2 ? 4 : RR;         // rows per staging unit
+    // rows per staging unit.  3 / 5 / 6 / 7 channels: 2 rows = 16 NCH bytes per frame = one 16-byte piece per lane -- every lane
+    // fetches the two slices of its OWN chain, one load instruction per unit
+    static constexpr int HR = NCH == 1 ? 4 : NCH == 2 ? 4 : POW2 ? RR : 2;
 #endif
-    static constexpr int PR = NCH == 1 ? 4 : NCH == 2 ? 2 : (RR < 4 ? RR : 4); // rows per phase (flush granularity)
+#ifndef QOA_K2G_PR // (tools/k2lab: rows per phase of the 3 / 5 / 6 / 7-channel geometry)
+#define QOA_K2G_PR 2
+#endif
+    static constexpr int PR = NCH == 1 ? 4 : NCH == 2 ? 2 : POW2 ? (RR < 4 ? RR : 4) : QOA_K2G_PR; // rows per phase (flush granularity)
     static constexpr int PB = PR * 40 * NCH;             // PCM bytes per frame per phase
-    static constexpr int ring() { // whole lines, >= one phase + the largest carried partial line
+    static constexpr int ring() { // whole lines, >= one phase + the largest carried partial line, and a whole number of
+                                  // sample-times (2 NCH bytes): a lane's channel offset is added to a wrapped sample-time offset,
+                                  // so no sample-time may straddle the ring's end (1 / 2 / 4 / 8 channels: any line multiple)
         int carry = 0, k = 0, pos = 0;
         for (k = 0; k < RR / PR; k++) { pos += PB; int c = pos % 128; carry = c > carry ? c : carry; }
-        return (PB + carry + 127) / 128 * 128;
+        int unit = 128;
+        while (unit % (2 * NCH)) unit += 128;
+        return (PB + carry + unit - 1) / unit * unit;
     }
     static constexpr int RING = ring();
     // Ring stride per frame.  Mono: an odd number of dwords -- 32 frames of a half-wave scatter into 32 different banks.
@@ -472,6 +487,7 @@ struct K2uCfg {
 #else
     static constexpr int GSP = RING + (NCH == 1 ? 4 : 16);
 #endif
+    static constexpr int IMG_GROUPS = FPW + (LIVE < 64 ? 1 : 0); // + the spare image the mirror lanes scribble into
     // staging units in flight: the slices of unit n + NSLOT are requested at the top of unit n (each slot is one unit's
     // lane-linear LDS-DMA image)
 #ifdef QOA_K2U_NSLOT
@@ -494,11 +510,13 @@ struct K2uCfg {
         for (int k = 1; k <= NSLOT; k++) n += unit_stores(((u - k) % units + units) % units);
         return n;
     }
-    static constexpr int NLS = FPW / 8;                  // store instructions per line (8 lanes = one 128-byte line of one frame)
-    static constexpr int CB = HR * 8 * NCH;              // slice bytes per frame per staging unit (64 or 128)
+    static constexpr int NLS = (FPW + 7) / 8;            // store instructions per line (8 lanes = one 128-byte line of one frame);
+                                                         // when FPW is no multiple of 8 the last one runs under a lane mask
+    static constexpr int CB = HR * 8 * NCH;              // slice bytes per frame per staging unit (64 or 128; 16 NCH)
     static constexpr int LPC = CB / 16;                  // lanes per frame chunk
-    static constexpr int NLD = FPW * CB / 1024;          // load instructions per staging unit
+    static constexpr int NLD = (FPW * LPC + 63) / 64;    // load instructions per staging unit
     static constexpr int SSP = CB;                       // stage stride per frame: lane-linear, as the LDS-DMA writes it
+    static constexpr int SLOT = NLD * 1024;              // one unit's stage: every lane of every load instruction lands 16 bytes
     static constexpr int lines_done(int rows) { return (rows * 40 * NCH) / 128; } // lines complete after `rows` rows of the round
     // store instructions issued during staging unit u (rows [u*HR, (u+1)*HR) of the round)
     static constexpr int unit_stores(int u) {
@@ -507,7 +525,8 @@ struct K2uCfg {
             if ((row + 1) % PR == 0) n += (lines_done(row + 1) - lines_done(row + 1 - PR)) * NLS;
         return n;
     }
-    static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (FPW * CB) % 1024 == 0,
+    static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (RR * 40 * NCH) % 128 == 0 &&
+                      (POW2 ? (FPW * CB) % 1024 == 0 : (LPC == NCH && NLD == 1)),
                   "K2u geometry");
 };
 
@@ -523,8 +542,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                                                                      unsigned *__restrict__ mismatches) {
     typedef K2uCfg<NCH> C;
     constexpr int FPW = C::FPW, RR = C::RR, HR = C::HR, PR = C::PR, RING = C::RING, GSP = C::GSP, NLS = C::NLS, NLD = C::NLD,
-                  SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = FPW * SSP;
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][FPW * GSP + (NCH == 1 ? 12 : 16)];
+                  SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = C::SLOT, LIVE = C::LIVE;
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][C::IMG_GROUPS * GSP + (NCH == 1 ? 12 : 16)];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][NSLOT * SLOT];
     __shared__ uint2 s_mags[16];
     // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
@@ -540,13 +559,21 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     init_mag_table(s_mags); // (ends with the block barrier)
 
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned g = lane / NCH, c = lane % NCH;
+    // lanes beyond the wave's FPW frames (3 / 5 / 6 / 7 channels) MIRROR the lane NCH below them: the same frame, channel,
+    // slices, table lookups and guard votes -- they add nothing and change nothing -- but scatter into a spare image and
+    // serve no store role
+    const bool mirror = lane >= (unsigned)LIVE;
+    const unsigned g = (mirror ? lane - NCH : lane) / NCH, c = lane % NCH;
     const unsigned frame0 = (blockIdx.x * (unsigned)WPB + wave) * FPW;
-    if (frame0 + FPW > n_frames) return; // a wave of the last block beyond the table (behind the only barrier)
-    const DecChain fr = frames[frame0 + g];
+    if (frame0 >= n_frames) return; // a wave of the last block beyond the table (behind the only barrier)
+    // The table's last wave may hold fewer than FPW frames: its spare frame slots decode the wave's last frame once more --
+    // the same slices, the same image, the same line stores to the same addresses (identical bytes: benign) -- so that
+    // whatever is left of a batch does not need a launch of its own (it ran alone on the chip for a wave's lifetime: + 0.2 ms)
+    const unsigned n_here = min((unsigned)FPW, n_frames - frame0);
+    const DecChain fr = frames[frame0 + min(g, n_here - 1u)];
     const uint8_t *f = in + fr.frame_off;
     Lms l;
-    if ((fr.expect_hi | fr.expect_lo) != 0 && c == 0) {
+    if ((fr.expect_hi | fr.expect_lo) != 0 && c == 0 && !mirror && g < n_here) {
         unsigned hi = bswap32(*(const unsigned *)f), lo = bswap32(*(const unsigned *)(f + 4));
         if (hi != fr.expect_hi || lo != fr.expect_lo) atomicAdd(mismatches, 1u);
     }
@@ -559,7 +586,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 
     uint8_t *img = s_img[wave];
     uint8_t *stage = s_stage[wave];
-    const unsigned my_img = g * GSP + c * 2;
+    const unsigned my_img = (mirror ? (unsigned)FPW : g) * GSP + c * 2;
     const unsigned my_stage = g * SSP + c * 8;
     // load roles: lane fetches 16-byte piece (lane % LPC) of frame q*(64/LPC) + lane/LPC, q in 0..NLD-1
     // store roles: lane writes 16-byte piece (lane % 8) of a line of frame o*8 + lane/8, o in 0..NLS-1
@@ -569,14 +596,17 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         const unsigned long long my_out = (unsigned long long)(out + fr.out_off);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
-            const int from = (int)(((unsigned)(q * (64 / LPC)) + lane / (unsigned)LPC) * NCH) << 2;
+            // (lanes beyond the last frame's chunk -- only where NCH does not divide 64 -- fetch the last frame's piece again:
+            // it lands in the stage's spare lanes)
+            const unsigned lf = min((unsigned)(q * (64 / LPC)) + lane / (unsigned)LPC, (unsigned)(FPW - 1));
+            const int from = (int)(lf * NCH) << 2;
             const unsigned ilo = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)my_in);
             const unsigned ihi = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(my_in >> 32));
             in_ptr[q] = ((((unsigned long long)ihi) << 32) | ilo) + (lane % (unsigned)LPC) * 16u;
         }
 #pragma unroll
         for (int o = 0; o < NLS; o++) {
-            const int from = (int)(((unsigned)(o * 8) + lane / 8u) * NCH) << 2;
+            const int from = (int)(min((unsigned)(o * 8) + lane / 8u, (unsigned)(FPW - 1)) * NCH) << 2; // (masked roles: any valid address)
             const unsigned olo = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)my_out);
             const unsigned ohi = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(my_out >> 32));
             out_ptr[o] = ((((unsigned long long)ohi) << 32) | olo) + (lane % 8u) * 16u;
@@ -632,8 +662,12 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             if constexpr (row % HR == 0)
                 unit_top(std::integral_constant<int, row / HR>{}, round * UNITS + row / HR);
             {
-                static_assert(RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 4 ? QOA_DEC_ASM_RING_4
-                                                                                                      : QOA_DEC_ASM_RING_8),
+                static_assert(RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 3 ? QOA_DEC_ASM_RING_3
+                                       : NCH == 4 ? QOA_DEC_ASM_RING_4 : NCH == 5 ? QOA_DEC_ASM_RING_5 : NCH == 6 ? QOA_DEC_ASM_RING_6
+                                       : NCH == 7 ? QOA_DEC_ASM_RING_7 : QOA_DEC_ASM_RING_8) &&
+                                  RR == (NCH == 1 ? QOA_DEC_ASM_ROWS_1 : NCH == 2 ? QOA_DEC_ASM_ROWS_2 : NCH == 3 ? QOA_DEC_ASM_ROWS_3
+                                         : NCH == 4 ? QOA_DEC_ASM_ROWS_4 : NCH == 5 ? QOA_DEC_ASM_ROWS_5 : NCH == 6 ? QOA_DEC_ASM_ROWS_6
+                                         : NCH == 7 ? QOA_DEC_ASM_ROWS_7 : QOA_DEC_ASM_ROWS_8),
                               "generated image offsets");
                 const uint2 raw = unit_raw[row % HR];
                 unsigned force = 0, flag = 0;
@@ -652,14 +686,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                      : [rx] "v"(raw.x), [ry] "v"(raw.y), [tab] "s"(tab_lds), [grow] "s"(grow_lds), [img] "v"(img_lds),  \
                        [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [force] "s"(force)                            \
                      : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS);
-                    QOA_DEC_ROW_CASE(8, 0) QOA_DEC_ROW_CASE(8, 1)
-                    QOA_DEC_ROW_CASE(4, 0) QOA_DEC_ROW_CASE(4, 1) QOA_DEC_ROW_CASE(4, 2) QOA_DEC_ROW_CASE(4, 3)
-                    QOA_DEC_ROW_CASE(2, 0) QOA_DEC_ROW_CASE(2, 1) QOA_DEC_ROW_CASE(2, 2) QOA_DEC_ROW_CASE(2, 3)
-                    QOA_DEC_ROW_CASE(2, 4) QOA_DEC_ROW_CASE(2, 5) QOA_DEC_ROW_CASE(2, 6) QOA_DEC_ROW_CASE(2, 7)
-                    QOA_DEC_ROW_CASE(1, 0) QOA_DEC_ROW_CASE(1, 1) QOA_DEC_ROW_CASE(1, 2) QOA_DEC_ROW_CASE(1, 3)
-                    QOA_DEC_ROW_CASE(1, 4) QOA_DEC_ROW_CASE(1, 5) QOA_DEC_ROW_CASE(1, 6) QOA_DEC_ROW_CASE(1, 7)
-                    QOA_DEC_ROW_CASE(1, 8) QOA_DEC_ROW_CASE(1, 9) QOA_DEC_ROW_CASE(1, 10) QOA_DEC_ROW_CASE(1, 11)
-                    QOA_DEC_ROW_CASE(1, 12) QOA_DEC_ROW_CASE(1, 13) QOA_DEC_ROW_CASE(1, 14) QOA_DEC_ROW_CASE(1, 15)
+                    QOA_DEC_ROW_CASES // (generated: one case per (channel count, row of the round))
 #undef QOA_DEC_ROW_CASE
                     if (flag == 0) break;
                     // the cheap guard tripped (nothing was executed): exact test on the current weights
@@ -717,10 +744,23 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 static_for<0, NLS>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
+                    constexpr int valid = FPW - o * 8 < 8 ? FPW - o * 8 : 8; // frames this role group really has
 #pragma unroll
                     for (int ln = l0; ln < l1; ln++) {
-                        typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
-                        __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
+                        if constexpr (valid == 8) {
+                            typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
+                            __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
+                        } else {
+                            // the last role group of a frame count that is no multiple of 8: the same store under a lane mask
+                            // (always issued -- the vmcnt bookkeeping of the slice loads counts it -- with the idle octets off)
+                            unsigned long long keep;
+                            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_store_dwordx4 %1, %2, off offset:%4 nt\n\t"
+                                         "s_mov_b64 exec, %0"
+                                         : "=&s"(keep)
+                                         : "v"(out_ptr[o] + (unsigned)(ln * 128 / 4096 * 4096)), "v"(vv[o][ln - l0]),
+                                           "s"((1ull << (8 * valid)) - 1ull), "n"(ln * 128 % 4096) // (13-bit signed immediate)
+                                         : "memory");
+                        }
                     }
                 });
                 asm volatile("" ::: "memory");
@@ -728,7 +768,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             }
         });
 #pragma unroll
-        for (int o = 0; o < NLS; o++) out_ptr[o] += 640;
+        for (int o = 0; o < NLS; o++) out_ptr[o] += RR * 40 * NCH; // the round's PCM per frame (whole lines: 640 B, or 1920 .. 4480 B)
     }
 }
 
@@ -769,8 +809,7 @@ static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const
                                           unsigned *mismatches, hipStream_t stream) {
     constexpr unsigned FPW = 64 / NCH;
     constexpr unsigned W = QOA_K2U_WPB_OVERRIDE ? QOA_K2U_WPB_OVERRIDE : K2uCfg<NCH>::WPB;
-    const unsigned waves = n_frames / FPW; // the plan only puts whole wavefronts of frames into this table
-    if (waves * FPW != n_frames) return hipErrorInvalidValue;
+    const unsigned waves = (n_frames + FPW - 1) / FPW; // (the last wave's spare frame slots repeat its last frame)
     // ONE launch: the last block may be short of waves (they leave behind the table barrier).  A second, small launch for a
     // remainder runs after the first on the stream, alone on the chip, for as long as a full wave takes (+0.25 ms measured).
     // Work that does not give every CU a block (single clips) runs one wavefront per block, spread over the CUs.
@@ -786,11 +825,17 @@ static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const
 hipError_t launch_decode_uniform(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
                                  unsigned *mismatches, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
-    if (nch == 1) return launch_decode_uniform_n<1>(in, out, frames, n_frames, mismatches, stream);
-    if (nch == 2) return launch_decode_uniform_n<2>(in, out, frames, n_frames, mismatches, stream);
-    if (nch == 4) return launch_decode_uniform_n<4>(in, out, frames, n_frames, mismatches, stream);
-    if (nch == 8) return launch_decode_uniform_n<8>(in, out, frames, n_frames, mismatches, stream);
-    return hipErrorInvalidValue;
+    switch (nch) {
+    case 1: return launch_decode_uniform_n<1>(in, out, frames, n_frames, mismatches, stream);
+    case 2: return launch_decode_uniform_n<2>(in, out, frames, n_frames, mismatches, stream);
+    case 3: return launch_decode_uniform_n<3>(in, out, frames, n_frames, mismatches, stream);
+    case 4: return launch_decode_uniform_n<4>(in, out, frames, n_frames, mismatches, stream);
+    case 5: return launch_decode_uniform_n<5>(in, out, frames, n_frames, mismatches, stream);
+    case 6: return launch_decode_uniform_n<6>(in, out, frames, n_frames, mismatches, stream);
+    case 7: return launch_decode_uniform_n<7>(in, out, frames, n_frames, mismatches, stream);
+    case 8: return launch_decode_uniform_n<8>(in, out, frames, n_frames, mismatches, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *in, int16_t *out, const DecChain *frames,

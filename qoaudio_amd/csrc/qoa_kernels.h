@@ -14,6 +14,7 @@ namespace qoa {
 //             step: for launches with several wavefronts per SIMD)
 //       bit5: no cheap-quotient speculative steps (run_block_spec<true>)
 //       bit6: no penalty form   bit7: no 32-bit block statement   bit8: no helper wavefronts   bit9: helper wavefronts always
+//       bit10: no wide form
 // d_stats (may be null, 5 x u64; [3] += slices the cheap-quotient form declined, re-evaluated by the exact speculative form,
 //                        [4] += (wavefront, slice) pairs in which the cheap-quotient form marked a candidate): [0] += (chain, slice) pairs the packed path declined and the 32-bit path re-evaluated,
 //                        [1] += full slices evaluated by the 32-bit path because a chain's state was not admissible,
@@ -38,10 +39,10 @@ hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *d_in,
                                 const DecChain *d_frames, unsigned n_frames, unsigned *d_mismatches,
                                 uint8_t *d_scratch, hipStream_t stream);
 
-// K2u, the fast path for uniform frames (rows == 256, n_out == 5120) of 1, 2, 4 or 8 channels: n_frames must be a multiple
-// of 64 / nch (whole wavefronts), every frame's PCM address 16-byte aligned.  decode_uniform_group(nch) = that multiple
-// (0: no K2u for this channel count).
-constexpr unsigned decode_uniform_group(int nch) { return nch == 1 || nch == 2 || nch == 4 || nch == 8 ? 64u / (unsigned)nch : 0u; }
+// K2u, the fast path for uniform frames (rows == 256, n_out == 5120) of 1 .. 8 channels: n_frames must be a multiple
+// of floor(64 / nch) (whole wavefronts' worth of frames), every frame's PCM address 16-byte aligned.
+// decode_uniform_group(nch) = that multiple (0: no K2u for this channel count).
+constexpr unsigned decode_uniform_group(int nch) { return nch >= 1 && nch <= 8 ? 64u / (unsigned)nch : 0u; }
 hipError_t launch_decode_uniform(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames, unsigned n_frames,
                                  unsigned *d_mismatches, hipStream_t stream);
 

@@ -366,6 +366,37 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
     return done;
 }
 
+// The wide form (QOA_BLOCK_WIDE_ASM_TEXT, tools/gen_slice_asm.py: pk_block(wide=True), round 4): exact-quotient speculative
+// steps with the TRUE 64-bit rank (one error term per step instead of the saturating pair sum) and the weight energy sampled
+// at EVERY step -- 30 instructions per step.  For material whose winners' ranks exceed the saturating rank's exact range
+// (32767^2) and whose scalefactor-0/1 candidates wrap without a provable bound, but whose winners carry NO penalty:
+// full-scale noise (tools/k1lab/leaver_study.c: 92 % of its winners' ranks are beyond 32767^2, a candidate is marked in 48 % of
+// its slices with no bound at all, and no winner carries a penalty).  Before, that class ran on the 35-instruction full form.
+// With a sample at every step the two energy tests need no margins for unsampled steps (limq0 / winq0): the margins are what
+// made the 4-step forms miss on noise, whose winners are high scalefactors with large weight steps.  Declines (done < n, entry
+// state restored) when a winner's penalty is not zero or a candidate's energy left the packed window.
+__device__ __forceinline__ unsigned run_block_wide(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
+                                                   int sf, const StepConst &k, int limq0, int winq0, unsigned n, PkLms &pk) {
+    register unsigned w01 asm("v84") = pk.w01;
+    register unsigned w23 asm("v85") = pk.w23;
+    register unsigned pa asm("v86") = pk.pa;
+    register unsigned pb asm("v87") = pk.pb;
+    unsigned done, tmp;
+    asm volatile(QOA_BLOCK_WIDE_ASM_TEXT
+                 : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
+                 : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
+                   [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq0), [winq] "v"(winq0), [rnd] "s"(1 << 15),
+                   [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
+                 : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+                   "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+                   "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                   "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+                   "v124", "v125", "v126", "v127");
+    pk.w01 = w01; pk.w23 = w23; pk.pa = pa; pk.pb = pb;
+    return done;
+}
+
 // The penalty form (QOA_BLOCK_PEN_ASM_TEXT, tools/gen_slice_asm.py: pk_block(pen=True)): cheap-quotient steps WITH the penalty
 // arithmetic on every step; the rank is err^2 + penalty as the full form's, nothing about the penalty is speculated.  What
 // the block loop runs where the speculative forms miss (winners that carry a penalty: tonal passages) -- 27 instead of the
@@ -682,7 +713,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
         const unsigned w = wave * 2u + (is_helper ? 1u : 0u);
-        if (w < 4096u) stats[8 + w] = ((unsigned long long)(xcc & 15u) << 32) | hwid | (1ull << 63);
+        if (w < 4096u) stats[10 + w] = ((unsigned long long)(xcc & 15u) << 32) | hwid | (1ull << 63);
     }
     const unsigned long long hwid_t0 = __builtin_readcyclecounter();
 #endif
@@ -716,6 +747,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const bool allow_cheap = (flags & 32u) == 0; // bit 5: no cheap-quotient steps
     const bool allow_pen = (flags & 64u) == 0 && allow_cheap && allow_spec && !lds_tables; // bit 6: no penalty form
     const bool allow_b32 = (flags & 128u) == 0;  // bit 7: no 32-bit block statement (slices the packed forms decline go one by one)
+    const bool allow_wide = (flags & 1024u) == 0 && allow_spec && !lds_tables; // bit 10: no wide form (64-bit rank, energy at every step)
     const unsigned qtab_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&s_qtab[sf][8];
     int limq, winq;
     spec_limits(sf, limq, winq);
@@ -726,7 +758,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // From the second one in a row the form sits out, 4 blocks at first and twice as long each further time up to 64:
     // material that defeats a form does so for long stretches (tonal passages keep the weights at the penalty threshold for
     // seconds; full-scale noise and clipped material never leave it), an isolated miss costs the rest of its block only.
-    unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0, pk_cooldown = 0, pk_streak = 0;
+    unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0, pk_cooldown = 0, pk_streak = 0, wide_cooldown = 0, wide_streak = 0;
+    // the wide form's limits: the energy is sampled at every step, no margins (spec_limits)
+    const int limq0 = (int)(kPkEnergyLimit - (0x8ffll << 18)), winq0 = 1 << 18;
     // The steady state: no form sitting out, no streak running, every chain of the wave packed -- then a whole block goes to the
     // cheap-quotient statement behind ONE test (a lone wavefront pays ~25 cycles per branch and the ladder below has a dozen:
     // ~700 cycles per block, 1.6 % of the kernel, measured with tools/k1lab/stamps.py).  ok_blocks = the lane's number of whole
@@ -734,7 +768,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     const bool steady_flags = allow_packed && allow_spec && allow_cheap && !lds_tables && !force_tail_path;
     const unsigned full_blocks = samples / (20u * kBlockSlices);
 
-#ifdef QOA_LAB_STAMPS // stats[8..11]: wave cycles in the steps / rest of the slice loop / the whole statement / the kernel
+#ifdef QOA_LAB_STAMPS // stats[10..13]: wave cycles in the steps / rest of the slice loop / the whole statement / the kernel
     unsigned long long lab_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lab_t = 0;
 #define QOA_LAB_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); lab_acc[i] += t_ - lab_t; lab_t = t_; }
     const unsigned long long lab_k0 = __builtin_readcyclecounter();
@@ -953,6 +987,22 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                         pen_streak = 0;
                     }
                 }
+                if (j < kBlockSlices && allow_wide && wide_cooldown == 0) {
+                    // the penalty form declined (or sits out): ranks beyond the saturating rank's range, marked candidates
+                    // without a bound -- noise.  Penalty-free winners assumed, proven per slice (run_block_wide).
+                    const unsigned r = run_block_wide(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j, dummy_addr,
+                                                      sf, kc, limq0, winq0, kBlockSlices - j, pk);
+                    const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+                    j += rw;
+                    if (stats && lane == 0 && rw) atomicAdd(&stats[9], (unsigned long long)rw); // wavefront-slices the wide form settled
+                    if (j < kBlockSlices) { // a winner with a penalty, or a candidate beyond the packed window: the full form goes on
+                        if (stats && sf == 0) atomicAdd(&stats[8], 1ull);
+                        wide_streak = min(wide_streak + 1u, 6u);
+                        if (wide_streak >= 2u) wide_cooldown = (kSpecCooldownBlocks << (wide_streak - 2u)) + 1;
+                    } else {
+                        wide_streak = 0;
+                    }
+                }
                 if (j < kBlockSlices) {
                     const unsigned j0 = j;
                     j += run_block_pk(tile0 + 4u * kSliceDwords * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
@@ -980,6 +1030,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             if (cheap_cooldown) cheap_cooldown--;
             if (pen_cooldown) pen_cooldown--;
             if (pk_cooldown) pk_cooldown--;
+            if (wide_cooldown) wide_cooldown--;
             const unsigned unsteady = spec_cooldown | cheap_cooldown | pk_cooldown | spec_streak | (blk - last_cheap_decline <= 1u ? 1u : 0u);
             ok_blocks = steady_flags && packed && __builtin_amdgcn_readfirstlane((int)unsteady) == 0 ? full_blocks : 0u;
         }
@@ -1047,7 +1098,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         flush_block(out_tile, nblocks - 1); // the last (possibly partial) block
     }
 #ifdef QOA_LAB_HWID
-    if (stats && lane == 0 && wave < 2048u) stats[8 + 4096 + wave] = __builtin_readcyclecounter() - hwid_t0;
+    if (stats && lane == 0 && wave < 2048u) stats[10 + 4096 + wave] = __builtin_readcyclecounter() - hwid_t0;
 #endif
     if (packed) pk_unpack(pk, st);
     if (sf == 0) {
@@ -1057,9 +1108,9 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     }
 #ifdef QOA_LAB_STAMPS
     if (stats && lane == 0) {
-        atomicAdd(&stats[8], lab_acc[0]); atomicAdd(&stats[9], lab_acc[1]); atomicAdd(&stats[10], lab_acc[2]);
-        atomicAdd(&stats[11], __builtin_readcyclecounter() - lab_k0);
-        for (int i = 3; i < 8; i++) atomicAdd(&stats[9 + i], lab_acc[i]);
+        atomicAdd(&stats[10], lab_acc[0]); atomicAdd(&stats[11], lab_acc[1]); atomicAdd(&stats[12], lab_acc[2]);
+        atomicAdd(&stats[13], __builtin_readcyclecounter() - lab_k0);
+        for (int i = 3; i < 8; i++) atomicAdd(&stats[11 + i], lab_acc[i]);
     }
 #endif
 }

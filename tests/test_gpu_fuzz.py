@@ -55,7 +55,8 @@ def test_fuzz_ragged_batches_round_trip(gpu, oracle, seed):
         outs = []
         for fl in (0, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT, batch.PLAN_NO_BLOCK32,
                    batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32, batch.PLAN_CPW_4, batch.PLAN_CPW_4 | batch.PLAN_NO_HELPER,
-                   batch.PLAN_CPW_4 | batch.PLAN_NO_SPECULATION, batch.PLAN_NO_HELPER, batch.PLAN_CPW_2 | batch.PLAN_NO_HELPER):
+                   batch.PLAN_CPW_4 | batch.PLAN_NO_SPECULATION, batch.PLAN_NO_HELPER, batch.PLAN_CPW_2 | batch.PLAN_NO_HELPER,
+                   batch.PLAN_NO_WIDE_FORM):
             out = torch.zeros(oo, dtype=torch.uint8, device="cuda")
             batch.EncodePlan(clips, fl).run(pcm, out)
             torch.cuda.synchronize()

@@ -130,7 +130,7 @@ def test_config5_eight_channel_streaming(gpu, oracle):
 
 
 @pytest.mark.parametrize("flags", ["default", "classic", "cpw1", "cpw2", "cpw2_classic", "cpw4", "cpw4_classic", "cpw4_classic_step32", "cpw4_step32", "generic", "step32", "step32_slices", "noblock32", "nospec", "exactq", "ldsq",
-                                   "ldsq_cpw1"])
+                                   "ldsq_cpw1", "nowide"])
 def test_ragged_batch_all_paths(gpu, oracle, flags):
     """One plan with clips of different lengths AND channel counts; every chains-per-wavefront packing and the
     forced generic path must all produce the oracle's bytes."""
@@ -144,7 +144,7 @@ def test_ragged_batch_all_paths(gpu, oracle, flags):
           "step32_slices": batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32, "noblock32": batch.PLAN_NO_BLOCK32,
           "nospec": batch.PLAN_NO_SPECULATION, "exactq": batch.PLAN_EXACT_QUOTIENT,
           "ldsq": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_4,
-          "ldsq_cpw1": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_1}[flags]
+          "ldsq_cpw1": batch.PLAN_LDS_TABLES | batch.PLAN_CPW_1, "nowide": batch.PLAN_NO_WIDE_FORM}[flags]
     shapes = [(2, 5300), (1, 41), (2, 20), (3, 999), (2, 12000), (1, 6000), (8, 333), (2, 1), (1, 5120), (2, 5121),
               (5, 777), (2, 640), (1, 10240), (2, 319)]
     clips, pcm_parts, pcm_off, out_off = [], [], 0, 0
@@ -605,7 +605,7 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
     outs = []
     for flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_SPECULATION, batch.PLAN_FORCE_32BIT_STEP, batch.PLAN_EXACT_QUOTIENT,
                   batch.PLAN_NO_PENALTY_FORM, batch.PLAN_NO_BLOCK32, batch.PLAN_FORCE_32BIT_STEP | batch.PLAN_NO_BLOCK32,
-                  batch.PLAN_NO_HELPER):
+                  batch.PLAN_NO_HELPER, batch.PLAN_NO_WIDE_FORM):
         plan = batch.EncodePlan(clips, flags | batch.PLAN_COUNTERS)
         out = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
         plan.run(pcm, out)
@@ -615,7 +615,7 @@ def test_packed_path_is_taken_on_real_music(gpu, oracle, fixture_pcm):
         if flags == batch.PLAN_EXACT_QUOTIENT:
             assert cheap_declined == 0
             continue
-        if flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_HELPER):
+        if flags in (batch.PLAN_DEFAULT, batch.PLAN_NO_HELPER, batch.PLAN_NO_WIDE_FORM):
             print(f"fixture: {declined} declined + {unpacked} unpacked, {misses} speculation misses, {cheap_declined} "
                   f"cheap-quotient declines of {2 * ((n + 19) // 20)} slices")
             # the cheap-quotient form must carry real music: a scalefactor-0 candidate's quotient wraps to the opposite sign

@@ -183,7 +183,10 @@ def emit(name, lines):
 
 
 # (channels, rows per round, image ring bytes): must agree with K2uCfg in qoa_decode.hip (static_asserts there)
-GEOMETRY = {1: (16, 256), 2: (8, int(os.environ.get("QOA_DEC_RING2", "256"))), 4: (4, 640), 8: (2, 640)}   # (env: tools/k2lab variants)
+GEOMETRY = {1: (16, 256), 2: (8, int(os.environ.get("QOA_DEC_RING2", "256"))), 4: (4, 640), 8: (2, 640),   # (env: tools/k2lab variants)
+            # channel counts that do not divide a wavefront (round 4): rounds of 16 / gcd(channels, 16) rows, 2-row phases
+            # (ring = whole lines AND whole sample-times: the channel offset sits in %[img], outside the wrapped offset)
+            3: (16, 384), 5: (16, 640), 6: (8, 768), 7: (16, 896)}
 
 
 def render():
@@ -191,9 +194,14 @@ def render():
            "// QOA_DEC_ROW_TEXT_<channels>_<row of the round>: one slice row of K2u (20 samples of every chain of the wave) on",
            "// i16-packed weights / history; scratch v64-v94.  See the generator for operands and wait-state rules.",
            f"#define QOA_DEC_ROW_CLOBBERS " + ", ".join(f'"v{r}"' for r in CLOBBERS),
-           ] + ["#define QOA_DEC_ASM_RING_%d %d" % (n, GEOMETRY[n][1]) for n in GEOMETRY] + [""]
+           ] + ["#define QOA_DEC_ASM_RING_%d %d" % (n, GEOMETRY[n][1]) for n in sorted(GEOMETRY)] + [
+               "#define QOA_DEC_ASM_ROWS_%d %d" % (n, GEOMETRY[n][0]) for n in sorted(GEOMETRY)] + [
+               "// the kernel's dispatch over (channel count, row of the round): expands QOA_DEC_ROW_CASE(N, R) for every text below",
+               "#define QOA_DEC_ROW_CASES " + " ".join(f"QOA_DEC_ROW_CASE({n}, {r})" for n in sorted(GEOMETRY) for r in range(GEOMETRY[n][0])),
+               ""]
     n_lines = 0
-    for nch, (rows, ring_bytes) in GEOMETRY.items():
+    for nch, (rows, ring_bytes) in sorted(GEOMETRY.items()):
+        assert ring_bytes % 128 == 0 and (nch == 1 or ring_bytes % (2 * nch) == 0), (nch, ring_bytes)
         for row in range(rows):
             t = row_text(nch, row, ring_bytes)
             check_hazards(t)

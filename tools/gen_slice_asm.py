@@ -209,6 +209,12 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         slot_a, slot_b = None, None
     elif i == 0:
         slot_a, slot_b = f"v_mov_b32 {N['acca']}, 0" + N.get("fill", ""), f"v_mov_b32 {N['accb']}, 0" + N.get("fill", "")
+    elif spec and N.get("wide"):
+        # wide form: the true 64-bit rank, one error per step -- sample i - 1 (a half of its pair register) minus its clamped
+        # reconstruction, the high half of the newest history pair B
+        slot_a = (f"v_sub_u32_sdwa {E}, sext(v{SPK0 + (i - 1) // 2}), sext({B}) dst_sel:DWORD dst_unused:UNUSED_PAD "
+                  f"src0_sel:WORD_{(i - 1) % 2} src1_sel:WORD_1")
+        slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}" + N.get("fill", "")
     elif spec:
         if N.get("alt") and i % 4 == 0:
             E = N["alt"][8]                                  # error pairs alternate between two registers
@@ -225,7 +231,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     # -- for the stretches where the speculation's premise (a penalty-free winner) does not hold: see pk_block.
     pen_steps = bool(N.get("pen_steps"))
     pen_full = not spec or pen_steps
-    check = spec and not pen_steps and i % 4 == 0
+    check = spec and not pen_steps and (i % 4 == 0 or bool(N.get("wide")))   # (the wide form samples the energy at every step)
     cheap = bool(N.get("cheap"))
     A1 = CH_A1[i % 2]
     PT = X if not pen_steps else PEN_TMP[i % 2]            # penalty temporary (the cheap steps keep X for their flag OR)
@@ -305,6 +311,11 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     L = [l for l in L if l is not None]
     if not spec:
         assert len(L) == 35
+        if i == 1:  # |err| of the first sample, right after slot_a produced it
+            k = L.index(slot_a) + 1
+            L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
+    elif N.get("wide"):
+        assert len(L) == 26 + 3 + (2 if i else 0)
         if i == 1:  # |err| of the first sample, right after slot_a produced it
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
@@ -593,7 +604,7 @@ def schedule(lines):
 LAB = set(filter(None, os.environ.get("QOA_GEN_LAB", "").split(",")))   # timing experiments (tools/k1lab/stamps.sh); never in the product
 
 
-def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, count=False):
+def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, count=False, wide=False):
     """Up to %[n] consecutive full slices of a block in one statement: candidate steps, winner election, exchange of
     the winner's state and staging of its slice, all through LDS; exits early (done < n) on a slice the packed path
     must decline, with the slice's entry state restored.
@@ -622,6 +633,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, coun
     falls back to where the speculative forms miss -- tonal passages, whose winners carry a penalty (3 % of real music's
     slices, clustered) -- instead of the 35-instruction full form."""
     assert not pen or (spec and cheap and not ldsq)
+    assert not wide or (spec and not cheap and not pen and not ldsq)
     stamps = "stamps" in LAB and cheap and not pen       # s90 = cycles in the 20 steps, s91 = cycles in the rest of the loop
     N = dict(PK_FIXED, **SPEC_REGS) if spec else PK_FIXED
     assert not spec or (N["R"][3], N["RC"][1], PK_S[2], PK_S[3]) == ("v92", "v93", "v94", "v95")   # = SLOT2
@@ -631,12 +643,12 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, coun
     CANDC, PADDR, THR, QM = "v65", "v64", "v119", N["qm"]
     cand = CANDC if spec else "%[cand]"
     reads = sample_reads(TCUR)
-    if spec:
+    if spec and not wide:
         K1 = ELO
     dpp = lambda r, n: f"v_min_u32_dpp {r}, {r}, {r} row_ror:{n} row_mask:0xf bank_mask:0xf"
     assert ELO == ELO_REG
     if spec:
-        return pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, dict(
+        return pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, dict(
             K1=K1, M=M, K2=K2, ADDR=ADDR, OADDR=OADDR, TCUR=TCUR, OCUR=OCUR, SHI=SHI, SLO=SLO, ELO=ELO, CANDC=CANDC,
             PADDR=PADDR, THR=THR, QM=QM, reads=reads, dpp=dpp))
     # ---- the full form ----
@@ -714,7 +726,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, coun
     return L
 
 
-def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
+def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
     """The speculative block loops (exact quotient, cheap quotient, LDS tables, penalty form).  ONE branch per slice:
     a not-taken s_cbranch_vccnz behind its v_cmp costs a lone wavefront ~24 cycles and a taken branch ~21
     (tools/ubench/branchbench.hip) -- the four exit tests of round 2's loop plus the loop branch were 4.6 % of the slice.
@@ -739,7 +751,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
     WQ, MK = "v83", CH_BND                                   # v83: the rank's high dword in the full form, unused here
     if cheap:
         K1 = "v116"                                          # the election's copy of the rank (a v_dot2's result may not be overwritten so soon)
-    LQ = QM if pen else N["pen"]                             # a register the form does not use otherwise
+    LQ = QM if pen else ("%[limq]" if wide else N["pen"])    # a register the form does not use otherwise
     QMV = N["pen"] if pen else QM
     LIMV = "%[limitv]"                                       # penalty form: kPkPenLimit in a VGPR (v_cndmask reads vcc: no SGPR source besides)
     cmp_ge = "v_cmp_ge_u32" if pen else "v_cmp_ge_i32"
@@ -762,12 +774,12 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
         # the winner's state; a slice-word store may trail, and SLOT2's read (waited for below)
         "s_waitcnt lgkmcnt(2)",
     ] + (["s_memtime s[86:87]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s86, s88", "s_add_u32 s91, s91, s92"] if stamps else []) + (
-        [f"v_mov_b32 {N['pen']}, 0"] if pen else [])
+        [f"v_mov_b32 {N['pen']}, 0"] if pen else []) + ([f"v_mov_b64 {N['e']}, 0"] if wide else [])
     body = []
     if ldsq:
         N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
     else:
-        N = dict(N, fill=FILL, cheap=cheap, pen_steps=pen, acc_cleared=True)
+        N = dict(N, fill=FILL, cheap=cheap, pen_steps=pen, acc_cleared=True, wide=wide)
     acc_line = None
     for i in range(20):
         if ldsq:
@@ -780,8 +792,13 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
         b2b = -1                                             # kept in program order (see pk_step_ldsq)
     else:
         E = N["alt"][8]                                      # pair 9: the odd pairs' register (pk_step)
-        body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,       # the last error pair (spec_rank_pair)
-                 f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL]
+        if wide:
+            body += [f"v_sub_u32_sdwa {E}, sext(v{SPK0 + 9}), sext({N['R'][0]}) dst_sel:DWORD dst_unused:UNUSED_PAD "
+                     f"src0_sel:WORD_1 src1_sel:WORD_1",                           # the last error (pk_step, wide)
+                     f"v_mad_i64_i32 {N['e']}, vcc, {E}, {E}, {N['e']}" + FILL]
+        else:
+            body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,   # the last error pair (spec_rank_pair)
+                     f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL]
         if not cheap:                                                              # (the cheap forms switch in an election gap)
             body.append(f"v_xor_b32 {CANDC}, %[pp], {CANDC}" + FILL)              # the other slot buffer: the entry state stays put
         if cheap:                                                                  # marked lanes (cheap_quotient_note): the sign
@@ -804,8 +821,16 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
     # ---- election, exchange, the one exit test ----
     # ELO's last writer is a v_dot2 (or the penalty form's v_add): three instructions go in front of its first reader
     WQr = WQ if cheap else ("%[winq]" if not pen else LIMV)
+    if wide:   # the full form's keys: rank < 2^37 -> rank >> 5, then rank[6:0] : |err0| : sf << 5
+        L += [
+            f"v_alignbit_b32 {K1}, v83, {ELO}, 5",
+            f"v_lshlrev_b32 {K2}, 25, {ELO}",
+            f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
+            f"v_or_b32 {K2}, %[sf4], {K2}",
+        ]
+    else:
+        L.append(f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]")   # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
     L += [
-        f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]",      # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
         f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
     ]
@@ -833,8 +858,10 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, G):
         f"ds_write_b128 {CANDC}, v[84:87]",
         f"ds_write_b128 {CANDC}, {SLOT2} offset:16",
         dpp(K2, 8),
+    ] + (["s_nop 1"] if wide else [                          # (the wide form's rank is its true rank)
         f"v_cmp_le_u32 vcc, s94, {M}",                       # is the best rank its true rank?  (see spec_rank_pair)
         f"v_cndmask_b32 {LQ}, {LIMV if pen else '%[limq]'}, {CH_BIG}, vcc",
+    ]) + [
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
         "s_nop 0" if ldsq else f"v_mov_b32 {N['acca']}, 0",  # the next slice's word (pk_step: acc_cleared)
@@ -884,6 +911,7 @@ def render(verbose=False):
     blk_cheap = pk_block(verbose, spec=True, cheap=True)
     blk_cheap_count = pk_block(False, spec=True, cheap=True, count=True)
     blk_pen = pk_block(verbose, spec=True, cheap=True, pen=True)
+    blk_wide = pk_block(verbose, spec=True, wide=True)
     blk_32 = b32_block()
     out = ("// GENERATED by tools/gen_slice_asm.py -- do not edit.\n"
            "// QOA_SLICE_ASM_TEXT: 20 x 41-instruction candidate steps of one slice, full 32-bit weights.\n"
@@ -905,10 +933,13 @@ def render(verbose=False):
            + "// QOA_BLOCK_PEN_ASM_TEXT: the cheap-quotient loop WITH the penalty arithmetic on every step (27/step): what the\n"
            + "//   block loop falls back to where the speculative forms miss (winners that carry a penalty), before the full form.\n"
            + emit("QOA_BLOCK_PEN_ASM_TEXT", blk_pen) + "\n"
+           + "// QOA_BLOCK_WIDE_ASM_TEXT: exact-quotient speculative steps with the true 64-bit rank and the weight energy sampled at\n"
+           + "//   EVERY step (30/step): full-scale noise -- winners' ranks beyond 32767^2, marked candidates without a bound.\n"
+           + emit("QOA_BLOCK_WIDE_ASM_TEXT", blk_wide) + "\n"
            + "// QOA_BLOCK_32_ASM_TEXT: a loop over consecutive full slices on the 32-bit step (it cannot decline): the block loop's\n"
            + "//   last resort; state in v[84:91], fixed registers v72-v127.\n"
            + emit("QOA_BLOCK_32_ASM_TEXT", blk_32))
-    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap), len(blk_pen), len(blk_32))
+    return out, (len(lines), len(pk), len(blk), len(blk_spec), len(blk_ldsq), len(blk_cheap), len(blk_pen), len(blk_wide), len(blk_32))
 
 
 INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaudio_amd", "csrc", "qoa_slice_asm.inc")

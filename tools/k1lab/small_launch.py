@@ -31,12 +31,12 @@ forms = [("default", 0), ("no helper", B.PLAN_NO_HELPER),
 
 
 def placement(plan, n_waves_max=4096):
-    buf = (ctypes.c_uint64 * (8 + n_waves_max + 2048))()
-    _lib.lib().qoa_encode_plan_counters(plan._h, buf, 8 + n_waves_max + 2048)
+    buf = (ctypes.c_uint64 * (10 + n_waves_max + 2048))()
+    _lib.lib().qoa_encode_plan_counters(plan._h, buf, 10 + n_waves_max + 2048)
     simd = collections.defaultdict(list)
     cus = set()
     for w in range(n_waves_max):
-        v = buf[8 + w]
+        v = buf[10 + w]
         if not v >> 63:
             continue
         xcc, hw = (v >> 32) & 15, v & 0xffffffff
@@ -48,11 +48,11 @@ def placement(plan, n_waves_max=4096):
     # compute wavefronts by what else sits on their SIMD: cycles per slice (the launch lasts as long as its slowest wavefront)
     by = collections.defaultdict(list)
     for w in range(0, n_waves_max, 2):
-        v = buf[8 + w]
+        v = buf[10 + w]
         if v >> 63:
             hw = v & 0xffffffff
             key = "".join(sorted(simd[(((v >> 32) & 15, (hw >> 8) & 0xff), (hw >> 4) & 3)]))
-            by[key].append(buf[8 + 4096 + w // 2] / (frames * 256))
+            by[key].append(buf[10 + 4096 + w // 2] / (frames * 256))
     text += "; compute cycles/slice by SIMD population: " + ", ".join(
         f"{k}: n {len(v)} mean {sum(v) / len(v):.0f} max {max(v):.0f}" for k, v in sorted(by.items()))
     allv = sorted(x for v in by.values() for x in v)
@@ -62,12 +62,12 @@ def placement(plan, n_waves_max=4096):
     if os.environ.get("QOA_HWID_DETAIL") == "1":  # per workgroup: XCC / CU / SIMD of the compute and helper wavefront, compute cycles
         rows = []
         for w in range(0, n_waves_max, 2):
-            c, h = buf[8 + w], buf[8 + w + 1]
+            c, h = buf[10 + w], buf[10 + w + 1]
             if not c >> 63:
                 continue
             f = lambda v: f"x{(v >> 32) & 15} se{(v >> 13) & 7} cu{(v >> 8) & 15} simd{(v >> 4) & 3}"
             rows.append(f"      wg {w // 2}: compute {f(c)}" + (f"  helper {f(h)}" if h >> 63 else "") +
-                        f"  cycles/slice {buf[8 + 4096 + w // 2] / (frames * 256):.0f}")
+                        f"  cycles/slice {buf[10 + 4096 + w // 2] / (frames * 256):.0f}")
         text += "\n" + "\n".join(rows[:int(os.environ.get("QOA_HWID_ROWS", "16"))])
     return text
 
