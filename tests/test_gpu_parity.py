@@ -1012,9 +1012,10 @@ def test_host_decode_pipeline_and_persistent_handle(gpu, oracle, pinned):
     assert np.array_equal(rb.numpy()[:parts[0].size], oracle.decode_all(host_enc[:rclips[1][1]].tobytes())[2])
 
 
-@pytest.mark.parametrize("channels", [1, 2, 4, 8])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_k2u_hostile_full_frames(gpu, oracle, channels):
-    """K2u (the fast path for full 256-row frames of 1 / 2 / 4 / 8 channels) on streams no encoder writes: random LMS headers and
+    """K2u (the fast path for full 256-row frames; round 4: every channel count 1 .. 8 -- with 3 / 5 / 6 / 7 channels a wavefront
+    holds floor(64 / channels) frames and its spare lanes mirror lanes of the last one) on streams no encoder writes: random LMS headers and
     random slices (weights race out of i16 and back), frames that start from extreme header weights and push them further
     with all-ones slices, quiet music in between -- enough full frames for several wavefronts of the fast path plus a rest
     that takes the general kernel.  Every stream must equal the oracle's decoder sample for sample: the generated row's
@@ -1052,6 +1053,35 @@ def test_k2u_hostile_full_frames(gpu, oracle, channels):
     for st, o, n in zip(streams, offs_out, plan.samples_out):
         _, _, want = oracle.decode_all(st)
         assert n == len(want) and np.array_equal(host[o:o + n], want)
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 5, 6, 7, 8])
+def test_k2u_partial_last_wavefront_beside_the_general_kernel(gpu, oracle, channels):
+    """Uniform clips whose full frames do not fill whole wavefronts (K2u's last wavefront repeats its last frame in the spare
+    frame slots: the same bytes to the same addresses) and that end in a short frame (the general kernel, launched BESIDE K2u
+    on the plan's side stream and joined before the caller's stream goes on): the same plan run several times back to back
+    into fresh buffers, a consumer kernel on the caller's stream right behind every run."""
+    from qoaudio_amd import batch
+    fpw = 64 // channels
+    n_clips, frames = 3, fpw + 1 + (channels % 3)                # 3 * frames full frames: never a multiple of fpw here
+    assert (n_clips * frames) % fpw != 0
+    samples = frames * 5120 + 3082 - (3082 % 8)                  # + a short last frame; clip PCM stays on the 16-byte grid
+    desc = gpu.QoaDesc(channels, 32000, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
+    assert (per_pcm * 2) % 16 == 0
+    pcm = np.stack([rng_pcm(500 + 7 * channels + i, per_pcm, "mix") for i in range(n_clips)])
+    enc = np.stack([np.frombuffer(oracle.encode_all(pcm[i], channels, 32000, samples), np.uint8) for i in range(n_clips)])
+    want = np.stack([oracle.decode_all(enc[i].tobytes())[2] for i in range(n_clips)])
+    d_enc = torch.from_numpy(enc).cuda()
+    plan = batch.DecodePlan.from_clips(clips)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for rep in range(4):
+            back = torch.full((n_clips, per_pcm), 12345, dtype=torch.int16, device="cuda")
+            plan.run(d_enc, back, stream)
+            copy = back.clone()                                   # on the caller's stream, right behind the run
+            assert np.array_equal(copy.cpu().numpy(), want), (channels, rep)
+    assert plan.mismatches() == 0
 
 
 def test_decode_plan_with_a_pcm_pointer_off_the_16_byte_grid(gpu, oracle):
