@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -818,7 +819,7 @@ struct DecTables {
     unsigned n_frames[kMaxChannels + 1] = {0};
     bool whole_pieces[kMaxChannels + 1] = {false};
     // K2u (qoa_decode.hip): uniform full frames (256 rows, 5120 sample-times) of 1 .. 8 channels whose PCM sits at a multiple
-    // of 16 bytes; everything else stays in frames[] for the general kernel
+    // of 4 bytes; everything else stays in frames[] for the general kernel
     DevBuf uframes[kMaxChannels + 1];
     // The general kernel's launches (short last frames of clips, odd alignments) run BESIDE K2u's on a side stream: behind it
     // on the same stream a few hundred short frames kept the chip for a wavefront's lifetime (0.2-0.6 ms) on their own.
@@ -859,9 +860,10 @@ struct DecTables {
             if (!decode_uniform_group(n)) continue;
             std::vector<DecChain> rest;
             for (const DecChain &d : per[n]) {
-                // (K2u's line stores need the 16-byte grid: tried with dword-aligned PCM in round 4 -- 128-byte runs that straddle
-                // two lines -- it ran 1.4-1.6x SLOWER than the general kernel: 2.07 vs 1.44 ms on 2048 stereo clips x 64 frames)
-                const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 16 == 0;
+                // (K2u's 16-byte stores want a dword-aligned PCM address.  On the 128-byte grid its runs are whole cache lines,
+                // streamed; off it the kernel switches to write-back stores: as streamed stores they ran 1.4-1.6x SLOWER than
+                // the general kernel, 2.07 vs 1.44 ms on 2048 stereo clips x 64 frames)
+                const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 4 == 0;
                 (uniform ? uni[n] : rest).push_back(d);
             }
             per[n].swap(rest); // (K2u's last wave may be short of frames: nothing is left over for a launch of its own)
@@ -910,7 +912,9 @@ struct DecTables {
         bool has_u = false, has_g = n_chains != 0;
         for (int n = 1; n <= kMaxChannels; n++) { has_u = has_u || n_uframes[n]; has_g = has_g || n_frames[n]; }
         hipStream_t gs = stream; // where the general kernel's launches go
-        if (has_u && has_g) {
+        static const int lab_side = getenv("QOA_LAB_DEC_SIDE") ? atoi(getenv("QOA_LAB_DEC_SIDE")) : 1; // (tools/k2lab: 0 = one stream, 2 = skip the general kernel)
+        if (lab_side == 2) has_g = false;
+        if (has_u && has_g && lab_side == 1) {
             hipError_t e = hipSuccess;
             if (!side) e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
             if (e == hipSuccess && !ev_fork) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
@@ -920,20 +924,20 @@ struct DecTables {
             if (e != hipSuccess) return e;
             gs = side;
         }
-        for (int n = 1; n <= kMaxChannels; n++) {
+        for (int n = 1; n <= kMaxChannels && lab_side != 2; n++) {
             hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n], counter,
                                                 (uint8_t *)mismatch.p + 64, gs);
             if (e != hipSuccess) return e;
         }
-        {
+        if (lab_side != 2) {
             hipError_t e = launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, counter, gs);
             if (e != hipSuccess) return e;
         }
         for (int n = 1; n <= kMaxChannels; n++) {
             if (!n_uframes[n]) continue;
-            // K2u stores 16-byte pieces at frame offsets that are multiples of 16: with an odd base pointer (a caller's
-            // sub-buffer) the same table goes through the general kernel instead
-            hipError_t e = ((uintptr_t)d_out % 16 == 0)
+            // K2u stores 16-byte pieces at dword-aligned addresses: with a base pointer off the dword grid (a caller's sub-buffer)
+            // the same table goes through the general kernel instead
+            hipError_t e = ((uintptr_t)d_out % 4 == 0)
                                ? launch_decode_uniform(n, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n], counter, stream)
                                : launch_decode_frames(n, true, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n], counter,
                                                       (uint8_t *)mismatch.p + 64, stream);

@@ -223,6 +223,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     init_deq_table(s_deq);
     init_mag_table(s_mags); // (ends with the block barrier)
 
+    // This kernel's launches usually run BESIDE a K2u launch that fills the chip (short last frames of the same batch, on the
+    // plan's side stream): its few wavefronts are serial chains of up to 256 rows, and sharing a SIMD's issue slots evenly with
+    // three K2u wavefronts stretched them from 0.14 ms to 1-2 ms -- the whole decode then waited for them.  They issue first.
+    __builtin_amdgcn_s_setprio(2);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned g = lane / NCH, c = lane % NCH;
     const unsigned frame_id = (blockIdx.x * (unsigned)WPB + wave) * FPW + g;
@@ -564,7 +568,21 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     // serve no store role
     const bool mirror = lane >= (unsigned)LIVE;
     const unsigned g = (mirror ? lane - NCH : lane) / NCH, c = lane % NCH;
-    const unsigned frame0 = (blockIdx.x * (unsigned)WPB + wave) * FPW;
+    // XCD-aware order: the dispatcher deals workgroups to the chip's 8 XCDs round-robin (workgroup b runs on XCD b % 8:
+    // tools/k1lab/small_launch.py stamps it), so with the identity mapping every XCD -- its L2, its translation caches -- walks
+    // the whole batch interleaved with the others.  Here XCD x takes the x-th contiguous eighth of the blocks instead (the
+    // first nb % 8 eighths hold one block more, exactly what round-robin dealing gives XCD x): -2 .. -4 % on config 3's decode,
+    // -1 .. -3 % mono, same buffers, alternating builds (tools/k2lab/ab_inproc.py, profiles/r04_k2lab_log.md).
+#if defined(QOA_K2U_XCD_CHUNK) // (tools/k2lab: XCD x takes chunks of QOA_K2U_XCD_CHUNK consecutive blocks, the XCDs move through the batch together)
+    const unsigned loc = blockIdx.x / 8u, xcd = blockIdx.x % 8u;
+    const unsigned bid = (loc / QOA_K2U_XCD_CHUNK) * (8u * QOA_K2U_XCD_CHUNK) + xcd * QOA_K2U_XCD_CHUNK + loc % QOA_K2U_XCD_CHUNK;
+#elif !defined(QOA_K2U_NO_XCD_ORDER)
+    const unsigned nb = gridDim.x, xcd = blockIdx.x % 8u, base = nb / 8u, extra = nb % 8u;
+    const unsigned bid = xcd * base + min(xcd, extra) + blockIdx.x / 8u;
+#else
+    const unsigned bid = blockIdx.x;
+#endif
+    const unsigned frame0 = (bid * (unsigned)WPB + wave) * FPW;
     if (frame0 >= n_frames) return; // a wave of the last block beyond the table (behind the only barrier)
     // The table's last wave may hold fewer than FPW frames: its spare frame slots decode the wave's last frame once more --
     // the same slices, the same image, the same line stores to the same addresses (identical bytes: benign) -- so that
@@ -612,6 +630,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             out_ptr[o] = ((((unsigned long long)ohi) << 32) | olo) + (lane % 8u) * 16u;
         }
     }
+    // do all of the wave's frames start on a 128-byte line?  (decides the store policy of the flush, wave-uniform)
+    const bool lines_aligned = __builtin_amdgcn_ballot_w64((((unsigned long long)(out + fr.out_off)) & 127ull) != 0ull) == 0ull;
     const unsigned oct_img = (lane / 8u) * GSP + (lane % 8u) * 16u;                       // + o*8*GSP + ring offset of the line
     typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
 
@@ -742,6 +762,13 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     }
                 });
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // Frames on the 128-byte grid: every store instruction covers whole cache lines -- streamed past L2 (nt).  Off it
+                // every 128-byte run straddles two lines, each half written by a different instruction: as write-back stores the
+                // halves meet in L2 (63 full stereo frames per clip, PCM 48 bytes off the grid: 0.98 -> 0.61 ms; on the grid nt is
+                // the faster one, 0.44 vs 0.45 ms -- tools/k2lab/short_frames.py).  Two copies of the burst, one wave-uniform
+                // branch in front: each stays straight-line code inside the raised-priority window (tests/test_k2_disasm.py).
+                auto store_burst = [&](auto streamed) {
+                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO); // (again: each copy is a window of its own)
                 static_for<0, NLS>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
                     constexpr int valid = FPW - o * 8 < 8 ? FPW - o * 8 : 8; // frames this role group really has
@@ -749,7 +776,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     for (int ln = l0; ln < l1; ln++) {
                         if constexpr (valid == 8) {
                             typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
-                            __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
+                            if constexpr (decltype(streamed)::value) __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
+                            else *(gptr_t)(out_ptr[o] + ln * 128) = vv[o][ln - l0];
                         } else {
                             // the last role group of a frame count that is no multiple of 8: the same store under a lane mask
                             // (always issued -- the vmcnt bookkeeping of the slice loads counts it -- with the idle octets off)
@@ -759,12 +787,15 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                                          : "=&s"(keep)
                                          : "v"(out_ptr[o] + (unsigned)(ln * 128 / 4096 * 4096)), "v"(vv[o][ln - l0]),
                                            "s"((1ull << (8 * valid)) - 1ull), "n"(ln * 128 % 4096) // (13-bit signed immediate)
-                                         : "memory");
+                                         : "memory"); // (always nt: a handful of lanes)
                         }
                     }
                 });
                 asm volatile("" ::: "memory");
                 if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+                };
+                if (lines_aligned) store_burst(std::true_type{});
+                else store_burst(std::false_type{});
             }
         });
 #pragma unroll
@@ -841,6 +872,12 @@ hipError_t launch_decode_uniform(int nch, const uint8_t *in, int16_t *out, const
 hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *in, int16_t *out, const DecChain *frames,
                                 unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
+    // few wavefronts (the short last frames of a batch): one per workgroup, so that they spread over the compute units
+    const unsigned waves = (n_frames + (64u / (unsigned)nch) - 1) / (64u / (unsigned)nch);
+    if (waves < 1024u) {
+        if (whole_pieces) return launch_decode_frames_r<4, 1, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
+        return launch_decode_frames_r<4, 1, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
+    }
     if (whole_pieces) return launch_decode_frames_r<4, 4, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
     return launch_decode_frames_r<4, 4, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
 }

@@ -173,7 +173,7 @@ def test_k2u_flush_stores_issue_at_raised_priority(kernels):
                 prio = int(i.split()[1])
             elif op.startswith(("s_cbranch", "s_branch")) and prio:
                 prio = prio  # (the window is straight-line code; a branch inside it would show up as plain stores below)
-            elif op == "global_store_dwordx4" and " nt" in i:
+            elif op == "global_store_dwordx4":   # streamed (nt: frames on the 128-byte grid) and write-back (off it) bursts alike
                 if prio:
                     raised_stores += 1
                 else:

@@ -23,7 +23,8 @@ for ch in [int(c) for c in os.environ.get('QOA_CHANNELS', '1,2,3,4,5,6,7,8').spl
     buf = torch.zeros(pcm.numel() + 8, dtype=torch.int16, device="cuda")
     import hashlib
     # the same plan into a 16-byte aligned buffer (K2u: uniform full frames) and into one 8 bytes off (the general kernel K2)
-    for name, back in (("K2u", buf[:pcm.numel()]), ("K2 (PCM base 8 bytes off the 16-byte grid)", buf[4:4 + pcm.numel()])):
+    for name, back in (("K2u", buf[:pcm.numel()]), ("K2u, PCM base 8 bytes off the 16-byte grid (write-back stores)", buf[4:4 + pcm.numel()]),
+                       ("K2 (PCM base 2 bytes off the dword grid)", buf[1:1 + pcm.numel()])):
         for _ in range(6):
             dplan.run(out, back)
         torch.cuda.synchronize()

@@ -11,12 +11,17 @@ from qoaudio_amd import batch, synth  # noqa: E402
 import qoaudio_amd as gpu  # noqa: E402
 
 n_clips, ch = int(os.environ.get("QOA_CLIPS", "1024")), 2
-for name, samples in (("63 full frames", 63 * 5120), ("one 3082-sample frame", 3082), ("one 3080-sample frame (whole 16-byte pieces)", 3080),
-                      ("63 full frames + 3082", 63 * 5120 + 3082), ("255 full frames + 3082", 255 * 5120 + 3082)):
+only = os.environ.get("QOA_ONLY")
+for idx, (name, samples) in enumerate((("63 full frames", 63 * 5120), ("one 3082-sample frame", 3082), ("one 3080-sample frame (whole 16-byte pieces)", 3080),
+                      ("63 full frames + 3082", 63 * 5120 + 3082), ("255 full frames + 3082", 255 * 5120 + 3082))):
+    if only is not None and str(idx) not in only.split(","):
+        continue
     desc = gpu.QoaDesc(ch, 44100, samples)
     clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
-    pcm = synth.make_clips(n_clips, samples, ch, 44100, device="cuda") if samples < 70 * 5120 else \
-        synth.make_clips(32, samples, ch, 44100, device="cuda").repeat((n_clips // 32, 1, 1)).contiguous()
+    pad = (-samples) % 4 if os.environ.get("QOA_PACKED") != "1" else 0   # stereo: 4 sample-times = 16 bytes
+    clips = [(k * (samples + pad) * ch, oo, dd) for k, (po, oo, dd) in enumerate(clips)]
+    pcm = synth.make_clips(n_clips, samples + pad, ch, 44100, device="cuda") if samples < 70 * 5120 else \
+        synth.make_clips(32, samples + pad, ch, 44100, device="cuda").repeat((n_clips // 32, 1, 1)).contiguous()
     enc = torch.empty((n_clips, per_enc), dtype=torch.uint8, device="cuda")
     batch.EncodePlan(clips).run(pcm, enc)
     dplan = batch.DecodePlan.from_clips(clips)
