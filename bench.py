@@ -314,6 +314,7 @@ def signal_classes(q, batch, synth, dev, stream, ch, rate, n_clips=256, frames=6
                      "counters": {"declined_slices": c[0], "unpacked_slices": c[1], "speculation_misses": c[2],
                                   "cheap_quotient_declines": c[3], "cheap_quotient_marked_candidates": c[4],
                                   "wavefront_slices_on_32bit_step": c[5], "penalty_form_declines": c[7],
+                                  "wide_form_declines": c[8], "wavefront_slices_on_wide_form": c[9],
                                   "slices_total": n_clips * ch * frames * 256}}
         del plan, cplan, pcm
     if "music" in res:

@@ -631,7 +631,11 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         }
     }
     // do all of the wave's frames start on a 128-byte line?  (decides the store policy of the flush, wave-uniform)
+#ifdef QOA_K2U_FORCE_WRITE_BACK // (tools/k2lab)
+    const bool lines_aligned = __builtin_amdgcn_ballot_w64(((unsigned long long)(out + fr.out_off)) != 0ull) == 0ull;
+#else
     const bool lines_aligned = __builtin_amdgcn_ballot_w64((((unsigned long long)(out + fr.out_off)) & 127ull) != 0ull) == 0ull;
+#endif
     const unsigned oct_img = (lane / 8u) * GSP + (lane % 8u) * 16u;                       // + o*8*GSP + ring offset of the line
     typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
 
@@ -768,6 +772,11 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 // the faster one, 0.44 vs 0.45 ms -- tools/k2lab/short_frames.py).  Two copies of the burst, one wave-uniform
                 // branch in front: each stays straight-line code inside the raised-priority window (tests/test_k2_disasm.py).
                 auto store_burst = [&](auto streamed) {
+                constexpr bool kStreamed = decltype(streamed)::value;
+                // (the two copies differ only in the stores' !nontemporal metadata: LLVM would merge them into one -- dropping the
+                // metadata, i.e. ALL stores write-back -- were it not for these comment-only statements that differ)
+                if constexpr (kStreamed) asm volatile("; K2u flush, streamed stores" ::: "memory");
+                else asm volatile("; K2u flush, write-back stores" ::: "memory");
                 if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO); // (again: each copy is a window of its own)
                 static_for<0, NLS>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
@@ -776,7 +785,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     for (int ln = l0; ln < l1; ln++) {
                         if constexpr (valid == 8) {
                             typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
-                            if constexpr (decltype(streamed)::value) __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
+                            if constexpr (kStreamed) __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
                             else *(gptr_t)(out_ptr[o] + ln * 128) = vv[o][ln - l0];
                         } else {
                             // the last role group of a frame count that is no multiple of 8: the same store under a lane mask
@@ -791,7 +800,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                         }
                     }
                 });
-                asm volatile("" ::: "memory");
+                if constexpr (kStreamed) asm volatile("; end of the streamed burst" ::: "memory");
+                else asm volatile("; end of the write-back burst" ::: "memory");
                 if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(0);
                 };
                 if (lines_aligned) store_burst(std::true_type{});

@@ -178,6 +178,11 @@ def test_k2u_flush_stores_issue_at_raised_priority(kernels):
                     raised_stores += 1
                 else:
                     plain_stores += 1
+        # both store policies ship: streamed (nt) for frames on the 128-byte grid, write-back off it (LLVM once merged the
+        # two bursts into one and dropped the nt hint with it)
+        nt = sum(1 for i in ins if i.split()[0] == "global_store_dwordx4" and " nt" in i)
+        wb = sum(1 for i in ins if i.split()[0] == "global_store_dwordx4" and " nt" not in i)
+        assert nt > 0 and wb > 0 and (nch not in (1, 2, 4, 8) or nt == wb), (name, nt, wb)
         if nch == 8:
             assert raised_stores == 0, name
         else:
