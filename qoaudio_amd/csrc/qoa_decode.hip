@@ -1,5 +1,11 @@
-// qoa_decode.hip -- K2, the gfx950 slice decoder (reference: decode_one_slice_per_channel src/lib.rs:291-330,
-// LMS read :271-281).  Split from qoa_kernels.hip (K1) so that the two kernels build independently.
+// qoa_decode.hip -- the gfx950 slice decoders (reference: decode_one_slice_per_channel src/lib.rs:291-330, LMS read
+// :271-281).  Three kernels, in the order of this file:
+//   qoa_decode_kernel          any channel count, one lane per chain, 2-byte stores: only for streams of more than 8 channels
+//   qoa_decode_frames_kernel   "K2", the general kernel for 1 .. 8 channels: short last frames, PCM off the dword grid; slices
+//                              fetched per lane into AccVGPRs, 16-byte pieces out of an LDS image
+//   qoa_decode_uniform_kernel  "K2u", the fast path that carries almost every frame: full 256-row frames of 1 .. 8 channels,
+//                              slices staged by LDS-DMA (no AccVGPRs), whole 128-byte lines out of an LDS ring, generated rows
+// Split from qoa_kernels.hip (K1) so that the kernels build independently.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -18,7 +24,7 @@ namespace qoa {
 
 
 // ------------------------------------------------------------------------------------------------
-// K2: decode
+// K2 (qoa_decode_frames_kernel; the description of the I/O below is this kernel's, K2u has its own further down)
 //
 // A decode chain is one (stream, frame, channel): the LMS state is re-seeded from every frame header
 // (src/lib.rs:270-281), so frames are independent.  One lane per chain, 20 steps per slice
@@ -299,6 +305,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     // load retired, the NP stores behind it still in flight.  hipcc cannot express that wait -- at the loop header
     // it merges the pre-loop state (loads only) with the back edge (loads + stores) into a near-zero count -- so
     // the loads and their waits are asm here, invisible to its vmcnt bookkeeping (the loop has no other loads).
+    // (This AccVGPR protocol is K2's only; K2u stages its slices by LDS-DMA and holds no load in a register.)
     // The destination of a load in flight must not be a register hipcc knows about: it believes an asm output is ready
     // when the statement ends and may copy or spill it before the data has arrived.  The slices therefore land in
     // AccVGPRs a[2k : 2k+1] (k = slot of (group set, row)), which hipcc never allocates in this kernel, and reach ordinary
@@ -417,10 +424,11 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2u: the fast path for UNIFORM frames -- rows == 256 and n_out == 5120 (every frame of a clip but its last), 1, 2, 4 or 8
-// channels (the divisors of a wavefront's 64 lanes), 16-byte aligned PCM.  Everything else (short frames, 3 / 5 / 6 / 7
-// channels, odd alignments) stays on qoa_decode_frames_kernel above; the plan splits its frame table accordingly
-// (qoa_capi.cpp, DecTables).
+// K2u: the fast path for UNIFORM frames -- rows == 256 and n_out == 5120 (every frame of a clip but its last), 1 .. 8
+// channels (round 4: also 3 / 5 / 6 / 7, whose frames do not fill a wavefront: K2uCfg, "mirror" lanes), PCM on a dword grid
+// (streamed stores on a 128-byte grid, write-back stores off it).  Short last frames and PCM off the dword grid stay on
+// qoa_decode_frames_kernel above; the plan splits its frame table accordingly (qoa_capi.cpp, DecTables) and launches that
+// kernel beside this one.
 //
 // What bounds it (profiles/r03_k2lab_log.md): the MEMORY SKELETON.  The same kernel with the sample arithmetic removed
 // (slice loads, stage, flush reads and stores only) takes as long as the whole kernel (1.5 ms on config 3); with the slices

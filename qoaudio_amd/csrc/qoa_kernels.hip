@@ -3,8 +3,7 @@
 // K1  qoa_encode_kernel : the 16-scalefactor brute-force slice search with the 4-tap sign-sign LMS
 //     recurrence (reference: encode_slice src/lib.rs:495-596, encode_frame_to_buf :441-493,
 //     QoaLms :797-829, qoa_div :613-617).
-// K2  qoa_decode_kernel : the slice decoder (reference: decode_one_slice_per_channel src/lib.rs:291-330,
-//     LMS read :271-281).
+// (K2 / K2u, the slice decoder, live in qoa_decode.hip.)
 //
 // Mapping (K1).  A chain = one (clip, channel) is strictly serial over its whole length because the
 // winner's end state of slice k is the entry state of slice k+1 (src/lib.rs:482) and the encoder
