@@ -461,6 +461,14 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 template <int NCH>
 struct K2uCfg {
     static constexpr bool POW2 = (NCH & (NCH - 1)) == 0; // 1, 2, 4, 8: the channels of a frame fill whole wavefronts
+    // bytes per flushed "line" and lanes per line.  128 / 8 everywhere in the product; the lab's mono variant (QOA_K2U_MONO_HALF:
+    // 64-byte half lines, a 128-byte ring per frame -> 12 instead of 8 wavefronts per CU) is measured in profiles/r04_k2lab_log.md
+#ifdef QOA_K2U_MONO_HALF
+    static constexpr int LNB = NCH == 1 ? 64 : 128;
+#else
+    static constexpr int LNB = 128;
+#endif
+    static constexpr int LPL = LNB / 16, FPS = 64 / LPL; // lanes per line, frames per store instruction
     static constexpr int FPW = 64 / NCH;                 // frames (groups) per wave; the 64 - FPW * NCH lanes beyond them (3, 5, 6, 7
                                                          // channels) mirror lanes of the last frame and write to a spare image
     static constexpr int LIVE = FPW * NCH;
@@ -478,15 +486,15 @@ struct K2uCfg {
 #ifndef QOA_K2G_PR // (tools/k2lab: rows per phase of the 3 / 5 / 6 / 7-channel geometry)
 #define QOA_K2G_PR 2
 #endif
-    static constexpr int PR = NCH == 1 ? 4 : NCH == 2 ? 2 : POW2 ? (RR < 4 ? RR : 4) : QOA_K2G_PR; // rows per phase (flush granularity)
+    static constexpr int PR = NCH == 1 ? (LNB == 64 ? 2 : 4) : NCH == 2 ? 2 : POW2 ? (RR < 4 ? RR : 4) : QOA_K2G_PR; // rows per phase (flush granularity)
     static constexpr int PB = PR * 40 * NCH;             // PCM bytes per frame per phase
     static constexpr int ring() { // whole lines, >= one phase + the largest carried partial line, and a whole number of
                                   // sample-times (2 NCH bytes): a lane's channel offset is added to a wrapped sample-time offset,
                                   // so no sample-time may straddle the ring's end (1 / 2 / 4 / 8 channels: any line multiple)
         int carry = 0, k = 0, pos = 0;
-        for (k = 0; k < RR / PR; k++) { pos += PB; int c = pos % 128; carry = c > carry ? c : carry; }
-        int unit = 128;
-        while (unit % (2 * NCH)) unit += 128;
+        for (k = 0; k < RR / PR; k++) { pos += PB; int c = pos % LNB; carry = c > carry ? c : carry; }
+        int unit = LNB;
+        while (unit % (2 * NCH)) unit += LNB;
         return (PB + carry + unit - 1) / unit * unit;
     }
     static constexpr int RING = ring();
@@ -522,14 +530,14 @@ struct K2uCfg {
         for (int k = 1; k <= NSLOT; k++) n += unit_stores(((u - k) % units + units) % units);
         return n;
     }
-    static constexpr int NLS = (FPW + 7) / 8;            // store instructions per line (8 lanes = one 128-byte line of one frame);
+    static constexpr int NLS = (FPW + FPS - 1) / FPS;    // store instructions per line (8 lanes = one 128-byte line of one frame);
                                                          // when FPW is no multiple of 8 the last one runs under a lane mask
     static constexpr int CB = HR * 8 * NCH;              // slice bytes per frame per staging unit (64 or 128; 16 NCH)
     static constexpr int LPC = CB / 16;                  // lanes per frame chunk
     static constexpr int NLD = (FPW * LPC + 63) / 64;    // load instructions per staging unit
     static constexpr int SSP = CB;                       // stage stride per frame: lane-linear, as the LDS-DMA writes it
     static constexpr int SLOT = NLD * 1024;              // one unit's stage: every lane of every load instruction lands 16 bytes
-    static constexpr int lines_done(int rows) { return (rows * 40 * NCH) / 128; } // lines complete after `rows` rows of the round
+    static constexpr int lines_done(int rows) { return (rows * 40 * NCH) / LNB; } // lines complete after `rows` rows of the round
     // store instructions issued during staging unit u (rows [u*HR, (u+1)*HR) of the round)
     static constexpr int unit_stores(int u) {
         int n = 0;
@@ -537,7 +545,7 @@ struct K2uCfg {
             if ((row + 1) % PR == 0) n += (lines_done(row + 1) - lines_done(row + 1 - PR)) * NLS;
         return n;
     }
-    static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (RR * 40 * NCH) % 128 == 0 &&
+    static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (RR * 40 * NCH) % LNB == 0 &&
                       (POW2 ? (FPW * CB) % 1024 == 0 : (LPC == NCH && NLD == 1)),
                   "K2u geometry");
 };
@@ -554,7 +562,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                                                                      unsigned *__restrict__ mismatches) {
     typedef K2uCfg<NCH> C;
     constexpr int FPW = C::FPW, RR = C::RR, HR = C::HR, PR = C::PR, RING = C::RING, GSP = C::GSP, NLS = C::NLS, NLD = C::NLD,
-                  SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = C::SLOT, LIVE = C::LIVE;
+                  SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = C::SLOT, LIVE = C::LIVE,
+                  LNB = C::LNB, LPL = C::LPL, FPS = C::FPS;
     __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][C::IMG_GROUPS * GSP + (NCH == 1 ? 12 : 16)];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][NSLOT * SLOT];
     __shared__ uint2 s_mags[16];
@@ -632,10 +641,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         }
 #pragma unroll
         for (int o = 0; o < NLS; o++) {
-            const int from = (int)(min((unsigned)(o * 8) + lane / 8u, (unsigned)(FPW - 1)) * NCH) << 2; // (masked roles: any valid address)
+            const int from = (int)(min((unsigned)(o * FPS) + lane / (unsigned)LPL, (unsigned)(FPW - 1)) * NCH) << 2; // (masked roles: any valid address)
             const unsigned olo = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)my_out);
             const unsigned ohi = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(my_out >> 32));
-            out_ptr[o] = ((((unsigned long long)ohi) << 32) | olo) + (lane % 8u) * 16u;
+            out_ptr[o] = ((((unsigned long long)ohi) << 32) | olo) + (lane % (unsigned)LPL) * 16u;
         }
     }
     // do all of the wave's frames start on a 128-byte line?  (decides the store policy of the flush, wave-uniform)
@@ -644,7 +653,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 #else
     const bool lines_aligned = __builtin_amdgcn_ballot_w64((((unsigned long long)(out + fr.out_off)) & 127ull) != 0ull) == 0ull;
 #endif
-    const unsigned oct_img = (lane / 8u) * GSP + (lane % 8u) * 16u;                       // + o*8*GSP + ring offset of the line
+    const unsigned oct_img = (lane / (unsigned)LPL) * GSP + (lane % (unsigned)LPL) * 16u; // + o*FPS*GSP + ring offset of the line
     typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
 
     // Asynchronous slice loads: LDS-DMA (global_load_lds_dwordx4) straight into the wave's stage -- lane L of instruction q
@@ -765,10 +774,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 #pragma unroll
                     for (int ln = l0; ln < l1; ln++) {
                         if constexpr (GSP % 16 == 0) {
-                            const u4_piece x = *(const u4_piece *)(img + oct_img + o * 8 * GSP + (ln * 128) % RING);
+                            const u4_piece x = *(const u4_piece *)(img + oct_img + o * FPS * GSP + (ln * LNB) % RING);
                             vv[o][ln - l0] = u4_unaligned{x[0], x[1], x[2], x[3]};
                         } else {
-                            const u32_alias *src = (const u32_alias *)(img + oct_img + o * 8 * GSP + (ln * 128) % RING);
+                            const u32_alias *src = (const u32_alias *)(img + oct_img + o * FPS * GSP + (ln * LNB) % RING);
                             vv[o][ln - l0] = u4_unaligned{src[0], src[1], src[2], src[3]};
                         }
                     }
@@ -788,13 +797,13 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO); // (again: each copy is a window of its own)
                 static_for<0, NLS>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
-                    constexpr int valid = FPW - o * 8 < 8 ? FPW - o * 8 : 8; // frames this role group really has
+                    constexpr int valid = FPW - o * FPS < FPS ? FPW - o * FPS : FPS; // frames this role group really has
 #pragma unroll
                     for (int ln = l0; ln < l1; ln++) {
-                        if constexpr (valid == 8) {
+                        if constexpr (valid == FPS) {
                             typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
-                            if constexpr (kStreamed) __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * 128));
-                            else *(gptr_t)(out_ptr[o] + ln * 128) = vv[o][ln - l0];
+                            if constexpr (kStreamed) __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * LNB));
+                            else *(gptr_t)(out_ptr[o] + ln * LNB) = vv[o][ln - l0];
                         } else {
                             // the last role group of a frame count that is no multiple of 8: the same store under a lane mask
                             // (always issued -- the vmcnt bookkeeping of the slice loads counts it -- with the idle octets off)
@@ -802,8 +811,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                             asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_store_dwordx4 %1, %2, off offset:%4 nt\n\t"
                                          "s_mov_b64 exec, %0"
                                          : "=&s"(keep)
-                                         : "v"(out_ptr[o] + (unsigned)(ln * 128 / 4096 * 4096)), "v"(vv[o][ln - l0]),
-                                           "s"((1ull << (8 * valid)) - 1ull), "n"(ln * 128 % 4096) // (13-bit signed immediate)
+                                         : "v"(out_ptr[o] + (unsigned)(ln * LNB / 4096 * 4096)), "v"(vv[o][ln - l0]),
+                                           "s"((1ull << (LPL * valid)) - 1ull), "n"(ln * LNB % 4096) // (13-bit signed immediate)
                                          : "memory"); // (always nt: a handful of lanes)
                         }
                     }

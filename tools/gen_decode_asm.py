@@ -183,7 +183,7 @@ def emit(name, lines):
 
 
 # (channels, rows per round, image ring bytes): must agree with K2uCfg in qoa_decode.hip (static_asserts there)
-GEOMETRY = {1: (16, 256), 2: (8, int(os.environ.get("QOA_DEC_RING2", "256"))), 4: (4, 640), 8: (2, 640),   # (env: tools/k2lab variants)
+GEOMETRY = {1: (16, int(os.environ.get("QOA_DEC_RING1", "256"))), 2: (8, int(os.environ.get("QOA_DEC_RING2", "256"))), 4: (4, 640), 8: (2, 640),   # (env: tools/k2lab variants)
             # channel counts that do not divide a wavefront (round 4): rounds of 16 / gcd(channels, 16) rows, 2-row phases
             # (ring = whole lines AND whole sample-times: the channel offset sits in %[img], outside the wrapped offset)
             3: (16, 384), 5: (16, 640), 6: (8, 768), 7: (16, 896)}
@@ -201,7 +201,7 @@ def render():
                ""]
     n_lines = 0
     for nch, (rows, ring_bytes) in sorted(GEOMETRY.items()):
-        assert ring_bytes % 128 == 0 and (nch == 1 or ring_bytes % (2 * nch) == 0), (nch, ring_bytes)
+        assert ring_bytes % 64 == 0 and (nch == 1 or (ring_bytes % 128 == 0 and ring_bytes % (2 * nch) == 0)), (nch, ring_bytes)
         for row in range(rows):
             t = row_text(nch, row, ring_bytes)
             check_hazards(t)
@@ -216,7 +216,7 @@ INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "qoaud
 def main():
     out, n = render()
     path = os.environ.get("QOA_GEN_OUT", INC_PATH)
-    assert path != INC_PATH or "QOA_DEC_RING2" not in os.environ, "lab geometry must not overwrite the product's rows"
+    assert path != INC_PATH or not ({"QOA_DEC_RING1", "QOA_DEC_RING2"} & set(os.environ)), "lab geometry must not overwrite the product's rows"
     with open(path, "w") as f:
         f.write(out)
     print(f"wrote {path}: {n} lines per row")
