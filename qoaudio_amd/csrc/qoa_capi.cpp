@@ -145,7 +145,7 @@ struct EncGroup {
 };
 
 #if defined(QOA_LAB_HWID)
-constexpr size_t kCounters = 10 + 4096 + 2048; // + one placement record per wavefront, cycles per compute wavefront (tools/k1lab/small_launch.py)
+constexpr size_t kCounters = 10 + 4096 + 2048 + 2048 * 8; // (+ 8 per-form counts per compute wavefront: tools/k1lab/forms.py) + one placement record per wavefront, cycles per compute wavefront (tools/k1lab/small_launch.py)
 #elif defined(QOA_LAB_STAMPS)
 constexpr size_t kCounters = 19; // + the timing experiment's (tools/k1lab/stamps.sh)
 #else
@@ -310,9 +310,9 @@ extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_s
 extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n) {
     if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
     if (!(plan->flags & QOA_PLAN_COUNTERS)) return fail_msg("plan was created without QOA_PLAN_COUNTERS", QOA_ENCODE_IO_ERROR);
-    uint64_t h[kCounters];
+    std::vector<uint64_t> h(kCounters);
     HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR);
-    HIP_TRY(hipMemcpy(h, plan->stats.p, sizeof h, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(h.data(), plan->stats.p, kCounters * sizeof(uint64_t), hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
     for (size_t i = 0; i < n; i++) out[i] = i < kCounters ? h[i] : 0;
     return QOA_OK;
 }

@@ -570,6 +570,13 @@ __device__ __forceinline__ unsigned pick_winner(unsigned long long e, unsigned p
 constexpr int kBlockSlices = 16;
 constexpr unsigned kHelperMaxWaves = 512; // launches up to this many compute wavefronts get helper wavefronts (1024 SIMDs)
 constexpr unsigned kSpecCooldownBlocks = 4; // blocks on the full step form after a speculation miss (misses cluster)
+#ifndef QOA_PK_COOLDOWN_BLOCKS // (tools/k1lab: the packed forms' back-off after a candidate left the i16 window)
+#define QOA_PK_COOLDOWN_BLOCKS 4
+#endif
+#ifndef QOA_PK_STREAK_MAX
+#define QOA_PK_STREAK_MAX 6
+#endif
+constexpr unsigned kPkCooldownBlocks = QOA_PK_COOLDOWN_BLOCKS, kPkStreakMax = QOA_PK_STREAK_MAX;
 constexpr unsigned kCheapCooldownBlocks = 4; // blocks on the exact-quotient form once the cheap-quotient form declined slices
                                              // in two consecutive blocks (or twice in one)
 // A slice's tile record is 12 dwords (three ds_read_b128): [0] marked_bound() of the slice, [1] unused, [2..11] its 20
@@ -715,6 +722,11 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
         if (w < 4096u) stats[10 + w] = ((unsigned long long)(xcc & 15u) << 32) | hwid | (1ull << 63);
     }
     const unsigned long long hwid_t0 = __builtin_readcyclecounter();
+    // per compute wavefront: wavefront-slices ATTEMPTED per form (a declined slice counts on the form that declined it too)
+    // 0 cheap, 1 exact-quotient speculative, 2 penalty, 3 wide, 4 full packed, 5 32-bit block, 6 slice loop, 7 blocks
+#define QOA_LAB_FORM(k, n) do { if (stats && lane == 0 && wave < 2048u) stats[10 + 4096 + 2048 + wave * 8u + (k)] += (unsigned long long)(n); } while (0)
+#else
+#define QOA_LAB_FORM(k, n) do { } while (0)
 #endif
     const int sf = (int)(lane & 15u);
     const unsigned row_base = lane & ~15u;
@@ -922,6 +934,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
             if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
             cheap_declined = j < kBlockSlices;
+            QOA_LAB_FORM(0, j + (cheap_declined ? 1u : 0u));
         }
         if (j < kBlockSlices) { // the ladder: a block whose 16 slices are full in every chain of the wave goes to block statements
             const bool whole = !force_tail_path && (unsigned long long)(k0 + kBlockSlices) * 20u <= samples;
@@ -947,8 +960,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                                     else
                                         j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
                                                                   dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk);
+                                    const unsigned j_was = j;
                                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
                                     if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
+                                    QOA_LAB_FORM(0, j - j_was + (j < kBlockSlices ? 1u : 0u));
                                 }
                                 cheap_declined = false;
                                 if (j == kBlockSlices) break;
@@ -962,6 +977,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                             r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
                             j += r;
                             proven = r == n_exact;
+                            QOA_LAB_FORM(1, r + (proven ? 0u : 1u));
                         }
                     }
                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: all forms return an SGPR)
@@ -978,6 +994,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     const unsigned r = run_block_pen(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j, dummy_addr,
                                                      sf, kc, kBlockSlices - j, pk);
                     j += (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+                    QOA_LAB_FORM(2, (unsigned)__builtin_amdgcn_readfirstlane((int)r) + (j < kBlockSlices ? 1u : 0u));
                     if (j < kBlockSlices) { // declined (loud material, weights beyond the packed window): the full form goes on
                         pen_streak = min(pen_streak + 1u, 6u);
                         if (pen_streak >= 2u) pen_cooldown = (kSpecCooldownBlocks << (pen_streak - 2u)) + 1;
@@ -993,6 +1010,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                                                       sf, kc, limq0, winq0, kBlockSlices - j, pk);
                     const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
                     j += rw;
+                    QOA_LAB_FORM(3, rw + (j < kBlockSlices ? 1u : 0u));
                     if (stats && lane == 0 && rw) atomicAdd(&stats[9], (unsigned long long)rw); // wavefront-slices the wide form settled
                     if (j < kBlockSlices) { // a winner with a penalty, or a candidate beyond the packed window: the full form goes on
                         if (stats && sf == 0) atomicAdd(&stats[8], 1ull);
@@ -1006,9 +1024,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     const unsigned j0 = j;
                     j += run_block_pk(tile0 + 4u * kSliceDwords * j0, cand_addr, outb_addr + 8u * j0, dummy_addr, sf, kc, kBlockSlices - j0, pk);
                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+                    QOA_LAB_FORM(4, j - j0 + (j < kBlockSlices ? 1u : 0u));
                     if (j < kBlockSlices) { // a candidate left the i16 window: the 32-bit statement (or the slice loop) goes on
-                        pk_streak = min(pk_streak + 1u, 6u);
-                        if (pk_streak >= 2u && allow_b32) pk_cooldown = (kSpecCooldownBlocks << (pk_streak - 2u)) + 1;
+                        pk_streak = min(pk_streak + 1u, kPkStreakMax);
+                        if (pk_streak >= 2u && allow_b32) pk_cooldown = (kPkCooldownBlocks << (pk_streak - 2u)) + 1;
                         if (allow_b32 && stats && sf == 0) atomicAdd(&stats[0], 1ull); // (else the slice loop below counts it)
                     } else {
                         pk_streak = 0;
@@ -1021,6 +1040,10 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                 if (packed) pk_unpack(pk, st);
                 else if (allow_packed && stats && sf == 0) atomicAdd(&stats[1], (unsigned long long)(kBlockSlices - j));
                 if (stats && lane == 0) atomicAdd(&stats[5], (unsigned long long)(kBlockSlices - j));
+                QOA_LAB_FORM(5, kBlockSlices - j);
+#ifdef QOA_LAB_HWID // (the lab's per-wavefront counts make the compiler lose sight of j's uniformity)
+                j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+#endif
                 run_block_32(tile0 + 4u * kSliceDwords * j, cand_addr, outb_addr + 8u * j, dummy_addr, sf, kc, kBlockSlices - j, st);
                 j = kBlockSlices;
                 packed = pk_try_pack(st, pk) && allow_packed;
@@ -1034,6 +1057,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
             ok_blocks = steady_flags && packed && __builtin_amdgcn_readfirstlane((int)unsteady) == 0 ? full_blocks : 0u;
         }
         QOA_LAB_MARK(6) // [6] the block statements and their dispatch
+        QOA_LAB_FORM(6, nj - j);
+        QOA_LAB_FORM(7, 1u);
         for (; j < nj; j++) {
             const int len = (int)min(samples - (k0 + j) * 20u, 20u);
             const bool full = (len == 20) && !force_tail_path;
