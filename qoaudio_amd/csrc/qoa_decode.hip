@@ -11,6 +11,7 @@
 
 #include "qoa_device.h"
 #include "qoa_kernels.h"
+#include <cstdlib>
 #ifndef QOA_DEC_ASM_INC
 #define QOA_DEC_ASM_INC "qoa_decode_asm.inc"
 #endif
@@ -479,9 +480,12 @@ struct K2uCfg {
 #ifdef QOA_K2U_HR2
     static constexpr int HR = NCH == 2 ? QOA_K2U_HR2 : NCH == 1 ? 4 : RR;
 #else
-    // rows per staging unit.  3 / 5 / 6 / 7 channels: 2 rows = 16 NCH bytes per frame = one 16-byte piece per lane -- every lane
-    // fetches the two slices of its OWN chain, one load instruction per unit
-    static constexpr int HR = NCH == 1 ? 4 : NCH == 2 ? 4 : POW2 ? RR : 2;
+    // rows per staging unit.  3 / 5 / 6 / 7 channels: 4 rows = 32 NCH bytes per frame and request (round 4; 2 rows -- one load
+    // instruction per unit -- were 2 .. 3.5 % slower on all four, 8 rows 1 .. 3 % slower: profiles/r04_k2lab_log.md section 7)
+#ifndef QOA_K2G_HR // (tools/k2lab: rows per staging unit of the 3 / 5 / 6 / 7-channel geometry)
+#define QOA_K2G_HR 4
+#endif
+    static constexpr int HR = NCH == 1 ? 4 : NCH == 2 ? 4 : POW2 ? RR : (QOA_K2G_HR <= RR ? QOA_K2G_HR : RR);
 #endif
 #ifndef QOA_K2G_PR // (tools/k2lab: rows per phase of the 3 / 5 / 6 / 7-channel geometry)
 #define QOA_K2G_PR 2
@@ -534,8 +538,9 @@ struct K2uCfg {
                                                          // when FPW is no multiple of 8 the last one runs under a lane mask
     static constexpr int CB = HR * 8 * NCH;              // slice bytes per frame per staging unit (64 or 128; 16 NCH)
     static constexpr int LPC = CB / 16;                  // lanes per frame chunk
-    static constexpr int NLD = (FPW * LPC + 63) / 64;    // load instructions per staging unit
-    static constexpr int SSP = CB;                       // stage stride per frame: lane-linear, as the LDS-DMA writes it
+    static constexpr int FPI = 64 / LPC;                 // whole frame chunks per load instruction (its other lanes land in spare room)
+    static constexpr int NLD = (FPW + FPI - 1) / FPI;    // load instructions per staging unit
+    static constexpr int SSP = CB;                       // stage stride per frame within an instruction's 1024 bytes: lane-linear, as the LDS-DMA writes it
     static constexpr int SLOT = NLD * 1024;              // one unit's stage: every lane of every load instruction lands 16 bytes
     static constexpr int lines_done(int rows) { return (rows * 40 * NCH) / LNB; } // lines complete after `rows` rows of the round
     // store instructions issued during staging unit u (rows [u*HR, (u+1)*HR) of the round)
@@ -546,7 +551,7 @@ struct K2uCfg {
         return n;
     }
     static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (RR * 40 * NCH) % LNB == 0 &&
-                      (POW2 ? (FPW * CB) % 1024 == 0 : (LPC == NCH && NLD == 1)),
+                      (POW2 ? (FPW * CB) % 1024 == 0 : LPC % NCH == 0) && LPC <= 64,
                   "K2u geometry");
 };
 
@@ -622,7 +627,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     uint8_t *img = s_img[wave];
     uint8_t *stage = s_stage[wave];
     const unsigned my_img = (mirror ? (unsigned)FPW : g) * GSP + c * 2;
-    const unsigned my_stage = g * SSP + c * 8;
+    const unsigned my_stage = (g / (unsigned)C::FPI) * 1024u + (g % (unsigned)C::FPI) * SSP + c * 8; // (= g * SSP where FPI chunks fill the 1024 bytes)
     // load roles: lane fetches 16-byte piece (lane % LPC) of frame q*(64/LPC) + lane/LPC, q in 0..NLD-1
     // store roles: lane writes 16-byte piece (lane % 8) of a line of frame o*8 + lane/8, o in 0..NLS-1
     unsigned long long in_ptr[NLD], out_ptr[NLS];
@@ -633,7 +638,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         for (int q = 0; q < NLD; q++) {
             // (lanes beyond the last frame's chunk -- only where NCH does not divide 64 -- fetch the last frame's piece again:
             // it lands in the stage's spare lanes)
-            const unsigned lf = min((unsigned)(q * (64 / LPC)) + lane / (unsigned)LPC, (unsigned)(FPW - 1));
+            const unsigned lf = min((unsigned)(q * C::FPI) + lane / (unsigned)LPC, (unsigned)(FPW - 1));
             const int from = (int)(lf * NCH) << 2;
             const unsigned ilo = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)my_in);
             const unsigned ihi = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(my_in >> 32));
@@ -871,8 +876,14 @@ static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const
     // ONE launch: the last block may be short of waves (they leave behind the table barrier).  A second, small launch for a
     // remainder runs after the first on the stream, alone on the chip, for as long as a full wave takes (+0.25 ms measured).
     // Work that does not give every CU a block (single clips) runs one wavefront per block, spread over the CUs.
+#ifdef QOA_K2U_LAB_DYNLDS // (tools/k2lab/generations.py: unused dynamic LDS per workgroup = fewer workgroups per CU)
+    const char *lab_lds = getenv("QOA_LAB_K2U_DYN_LDS");
+    const unsigned dyn_lds = lab_lds ? (unsigned)atoi(lab_lds) : 0u;
+#else
+    const unsigned dyn_lds = 0u;
+#endif
     if (waves >= 256u * W)
-        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, W>), dim3((waves + W - 1) / W), dim3(64 * W), 0, stream, in, out,
+        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, W>), dim3((waves + W - 1) / W), dim3(64 * W), dyn_lds, stream, in, out,
                            frames, n_frames, mismatches);
     else
         hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, 1>), dim3(waves), dim3(64), 0, stream, in, out, frames, n_frames,
