@@ -248,10 +248,12 @@ def general_decode(q, batch, synth, dev, stream, rate):
     res = {}
     for name, n_clips, ch, samples, pad in (("6ch", 682, 6, 64 * 5120, 0), ("3ch", 682, 3, 64 * 5120, 0),
                                             ("stereo_short_last_frame", 1024, 2, 63 * 5120 + 3082, 2),
-                                            ("stereo_short_last_frame_packed", 1024, 2, 63 * 5120 + 3082, 0)):
+                                            ("stereo_short_last_frame_packed", 1024, 2, 63 * 5120 + 3082, 0),
+                                            ("stereo_short_last_frame_line_aligned", 1024, 2, 63 * 5120 + 3082, 22)):
         # pad: extra sample-times per clip in the PCM tensor so that every clip starts on a 16-byte boundary (325,642 stereo
         # sample-times are 8 bytes short of one); packed = clips back to back: every second clip's PCM is 8 bytes off the
-        # grid and takes the general kernel for ALL of its frames
+        # 16-byte grid; line_aligned = every clip's PCM starts on a 128-byte line (the layout INTEGRATION.md recommends to callers
+        # who own it: the full frames then take the streamed-store path of K2u)
         desc = q.QoaDesc(ch, rate, samples)
         clips, _, per_enc = batch.uniform_clips(n_clips, desc)
         clips = [(k * (samples + pad) * ch, oo, dd) for k, (po, oo, dd) in enumerate(clips)]

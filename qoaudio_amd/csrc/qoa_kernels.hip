@@ -577,6 +577,13 @@ constexpr unsigned kSpecCooldownBlocks = 4; // blocks on the full step form afte
 #define QOA_PK_STREAK_MAX 6
 #endif
 constexpr unsigned kPkCooldownBlocks = QOA_PK_COOLDOWN_BLOCKS, kPkStreakMax = QOA_PK_STREAK_MAX;
+#ifndef QOA_SPEC_COOLDOWN_BLOCKS // (tools/k1lab: the speculative forms' back-off after a miss -- a winner that carries a penalty)
+#define QOA_SPEC_COOLDOWN_BLOCKS 4
+#endif
+#ifndef QOA_SPEC_STREAK_MAX
+#define QOA_SPEC_STREAK_MAX 6
+#endif
+constexpr unsigned kSpecMissCooldownBlocks = QOA_SPEC_COOLDOWN_BLOCKS, kSpecStreakMax = QOA_SPEC_STREAK_MAX;
 constexpr unsigned kCheapCooldownBlocks = 4; // blocks on the exact-quotient form once the cheap-quotient form declined slices
                                              // in two consecutive blocks (or twice in one)
 // A slice's tile record is 12 dwords (three ds_read_b128): [0] marked_bound() of the slice, [1] unused, [2..11] its 20
@@ -982,8 +989,8 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     }
                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j); // (wave-uniform: all forms return an SGPR)
                     if (j < kBlockSlices) { // slice j could not be proven: the penalty / full form takes over for the rest of the block
-                        spec_streak = min(spec_streak + 1u, 6u);
-                        if (spec_streak >= 2u) spec_cooldown = (kSpecCooldownBlocks << (spec_streak - 2u)) + 1;
+                        spec_streak = min(spec_streak + 1u, kSpecStreakMax);
+                        if (spec_streak >= 2u) spec_cooldown = (kSpecMissCooldownBlocks << (spec_streak - 2u)) + 1;
                         if (stats && sf == 0) atomicAdd(&stats[2], 1ull);
                     } else {
                         spec_streak = 0;
