@@ -606,6 +606,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 #endif
     const unsigned frame0 = (bid * (unsigned)WPB + wave) * FPW;
     if (frame0 >= n_frames) return; // a wave of the last block beyond the table (behind the only barrier)
+#ifdef QOA_K2U_LAB_STAGGER // (tools/k2lab: do the wavefronts of the first generation run in lockstep?  staggered starts, QOA_K2U_LAB_STAGGER x 3.4 us apart at most 8 steps)
+    for (unsigned k = (bid * 5u + wave * 3u) % 8u * QOA_K2U_LAB_STAGGER; k > 0; k--) __builtin_amdgcn_s_sleep(127);
+#endif
     // The table's last wave may hold fewer than FPW frames: its spare frame slots decode the wave's last frame once more --
     // the same slices, the same image, the same line stores to the same addresses (identical bytes: benign) -- so that
     // whatever is left of a batch does not need a launch of its own (it ran alone on the chip for a wave's lifetime: + 0.2 ms)

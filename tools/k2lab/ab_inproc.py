@@ -23,7 +23,7 @@ for n in names:
 L._lib = libs["product"]
 
 ch = int(os.environ.get("QOA_CH", "2"))
-n_clips, frames = 2048 // ch // 64 * 64, 256
+n_clips, frames = int(os.environ.get("QOA_CLIPS", 2048 // ch // 64 * 64)), 256
 samples = frames * 5120
 desc = gpu.QoaDesc(ch, 44100, samples)
 clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
