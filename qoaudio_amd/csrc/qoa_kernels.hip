@@ -968,6 +968,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                                         j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
                                                                   dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk);
                                     const unsigned j_was = j;
+                                    (void)j_was; // (the lab's per-wavefront counts)
                                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
                                     if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
                                     QOA_LAB_FORM(0, j - j_was + (j < kBlockSlices ? 1u : 0u));
