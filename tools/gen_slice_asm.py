@@ -233,6 +233,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     pen_full = not spec or pen_steps
     check = spec and not pen_steps and (i % 4 == 0 or bool(N.get("wide")))   # (the wide form samples the energy at every step)
     cheap = bool(N.get("cheap"))
+    acc_first = bool(N.get("acc_cleared")) and spec and i in (0, 10)
     A1 = CH_A1[i % 2]
     PT = X if not pen_steps else PEN_TMP[i % 2]            # penalty temporary (the cheap steps keep X for their flag OR)
     L = [
@@ -284,9 +285,11 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         # cheap forms: OR instead of add -- the same for a level, and a marked step sets bits 31..4 of the slice-word half: bit
         # 31 then stays set through the <= 9 shifts that follow (the run of ones always reaches it), which is the MARK the
         # election reads (round 3 OR-ed the steps' clamped quotients together: one v_or3 per step pair, 10 per slice)
-        f"v_lshl_or_b32 {acc}, {acc}, 3, {T}" if cheap else f"v_lshl_add_u32 {acc}, {acc}, 3, {T}",
+        # (acc_first: the first code of a slice-word half needs no shift -- and the half no clearing: code = 2 * level - sign in
+        # ONE instruction at steps 0 and 10, round 4)
+        None if acc_first else (f"v_lshl_or_b32 {acc}, {acc}, 3, {T}" if cheap else f"v_lshl_add_u32 {acc}, {acc}, 3, {T}"),
         f"v_perm_b32 {D}, %[dqhi], %[dqlo], {D}",
-        f"v_sub_u32 {acc}, {acc}, {SN}",
+        f"v_sub_u32 {acc}, {T if acc_first else acc}, {SN}",
     ] + ([
         f"v_xor_b32 {D}, {D}, {SN}",
         f"v_sub_u32 {D}, {D}, {SN}",                        # dequantised
@@ -315,13 +318,13 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     elif N.get("wide"):
-        assert len(L) == 26 + 3 + (2 if i else 0)
+        assert len(L) == 26 + 3 + (2 if i else 0) - (1 if acc_first else 0)
         if i == 1:  # |err| of the first sample, right after slot_a produced it
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
         assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0) - (
-            2 if i == 0 and N.get("acc_cleared") else 0)
+            2 if i == 0 and N.get("acc_cleared") else 0) - (1 if acc_first else 0)
         if i == 2:
             k = L.index(slot_b) + 1
             L[k:k] = spec_aerr0(N, E, CH_TMP if cheap else X)
@@ -864,9 +867,10 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
     ]) + [
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
-        "s_nop 0" if ldsq else f"v_mov_b32 {N['acca']}, 0",  # the next slice's word (pk_step: acc_cleared)
+        "s_nop 0",                                           # (round 3 cleared the next slice's word halves in these two gaps; pk_step's
+                                                             # acc_first makes that unnecessary)
         dpp(K2, 2),
-        "s_nop 0" if ldsq else f"v_mov_b32 {N['accb']}, 0",
+        "s_nop 0",
         f"v_mov_b32 {PADDR}, {ADDR}",                        # the slot that holds this slice's entry state (read if it is abandoned)
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {CANDC}",          # the winner's slot
