@@ -912,7 +912,11 @@ struct DecTables {
         bool has_u = false, has_g = n_chains != 0;
         for (int n = 1; n <= kMaxChannels; n++) { has_u = has_u || n_uframes[n]; has_g = has_g || n_frames[n]; }
         hipStream_t gs = stream; // where the general kernel's launches go
-        static const int lab_side = getenv("QOA_LAB_DEC_SIDE") ? atoi(getenv("QOA_LAB_DEC_SIDE")) : 1; // (tools/k2lab: 0 = one stream, 2 = skip the general kernel)
+#ifdef QOA_LAB_DEC_SIDE_KNOB // (tools/k2lab builds only: 0 = one stream, 2 = skip the general kernel -- wrong PCM, timing experiments)
+        static const int lab_side = getenv("QOA_LAB_DEC_SIDE") ? atoi(getenv("QOA_LAB_DEC_SIDE")) : 1;
+#else
+        constexpr int lab_side = 1;
+#endif
         if (lab_side == 2) has_g = false;
         if (has_u && has_g && lab_side == 1) {
             hipError_t e = hipSuccess;

@@ -214,7 +214,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         # reconstruction, the high half of the newest history pair B
         slot_a = (f"v_sub_u32_sdwa {E}, sext(v{SPK0 + (i - 1) // 2}), sext({B}) dst_sel:DWORD dst_unused:UNUSED_PAD "
                   f"src0_sel:WORD_{(i - 1) % 2} src1_sel:WORD_1")
-        slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {e}" + N.get("fill", "")
+        slot_b = f"v_mad_i64_i32 {e}, vcc, {E}, {E}, {0 if i == 1 else e}" + N.get("fill", "")   # (the first term starts the sum)
     elif spec:
         if N.get("alt") and i % 4 == 0:
             E = N["alt"][8]                                  # error pairs alternate between two registers
@@ -240,7 +240,8 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_dot2_i32_i16 {P}, {w01}, {A}, 0",
         f"v_dot2_i32_i16 {Q}, {w01}, {w01}, %[negc]" if pen_full or check else None,   # sum w^2 - (0x8ff << 18)
         f"v_dot2_i32_i16 {P}, {w23}, {B}, {P}",
-        f"v_dot2_i32_i16 {Q}, {w23}, {w23}, {Q}" if pen_full or check else None,
+        # (a sampling step's energy goes straight into the running maximum at step 0: no copy)
+        (f"v_dot2_i32_i16 {N['qm'] if check and i == 0 else Q}, {w23}, {w23}, {Q}") if pen_full or check else None,
         f"v_pk_ashrrev_i16 {SB}, 15, {B} op_sel_hi:[0,1]",   # the inline 15 has no high half to select
         slot_a,
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",  # (+-1, +-1) for B_n
@@ -251,8 +252,9 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_max_i32 {PT}, 0, {PT}" if pen_full else None,   # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1" if not cheap else f"v_ashrrev_i32 {SN}, 31, {T}",
-        f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}" if pen_full else None,
-        (f"v_mov_b32 {N['qm']}, {Q}" if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
+        ((f"v_mul_i32_i24 {pen}, {PT}, {PT}" if pen_steps and i == 0 else   # (penalty form: the first term starts the sum)
+          f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}") if pen_full else None),
+        (None if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
         f"v_ashrrev_i32 {U}, 16, {U}" if not cheap else None,
     ] + ([
         f"v_lshl_add_u32 {SN}, {T}, 1, {U}",
@@ -318,12 +320,12 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     elif N.get("wide"):
-        assert len(L) == 26 + 3 + (2 if i else 0) - (1 if acc_first else 0)
+        assert len(L) == 26 + (3 if i else 2) + (2 if i else 0) - (1 if acc_first else 0)
         if i == 1:  # |err| of the first sample, right after slot_a produced it
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
-        assert len(L) == (22 if cheap else 26) + (3 if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0) - (
+        assert len(L) == (22 if cheap else 26) + ((2 if i == 0 else 3) if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0) - (
             2 if i == 0 and N.get("acc_cleared") else 0) - (1 if acc_first else 0)
         if i == 2:
             k = L.index(slot_b) + 1
@@ -776,8 +778,8 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
         "Lqoa_top_%=:",
         # the winner's state; a slice-word store may trail, and SLOT2's read (waited for below)
         "s_waitcnt lgkmcnt(2)",
-    ] + (["s_memtime s[86:87]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s86, s88", "s_add_u32 s91, s91, s92"] if stamps else []) + (
-        [f"v_mov_b32 {N['pen']}, 0"] if pen else []) + ([f"v_mov_b64 {N['e']}, 0"] if wide else [])
+    ] + (["s_memtime s[86:87]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s86, s88", "s_add_u32 s91, s91, s92"] if stamps else [])
+    # (no per-slice clearing: the penalty sum, the wide form's rank and the slice-word halves all start with their first term)
     body = []
     if ldsq:
         N = dict(N, alt=None)                                # one temporary set: the steps are not interleaved
