@@ -835,10 +835,12 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
         ]
     else:
         L.append(f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]")   # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
-    L += [
-        f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
-        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
-    ]
+    # cheap forms without the marked-pair count: the slice word's halves are formed in wait-state gaps (the high half behind
+    # the rank's v_cndmask, the low half in the second reduction) instead of in slots of their own
+    late_words = cheap and not count
+    shi_line, slo_line = f"v_lshrrev_b32 {SHI}, 2, {N['acca']}", f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}"
+    if not late_words:
+        L += [shi_line, slo_line]
     # First reduction: M = the row's best rank.  A DPP read needs two instructions between it and the VALU write of its
     # source: the gaps hold the election's own bookkeeping -- slice-word head, tile / out-tile cursors, the next slice's three
     # sample reads, the switch to the other slot buffer.
@@ -846,10 +848,11 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
     xor_c = f"v_xor_b32 {CANDC}, %[pp], {CANDC}"             # the other slot buffer: the entry state stays put
     dpp8 = f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf"
     if cheap:
-        L += [
-            f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc",   # a marked candidate's rank: what it provably costs (real ranks count from 1)
-            f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc",   # ... and if that wins, the slice is abandoned
-        ]
+        k1_line = f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc"   # a marked candidate's rank: what it provably costs (real ranks count from 1)
+        wq_line = f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc"   # ... and if that wins, the slice is abandoned
+        # (the rank's last writer is a v_dot2 / the penalty form's v_add: three instructions stand between it and k1_line --
+        # the marks' v_cmp, the second key, and with late_words wq_line)
+        L += [wq_line, k1_line, shi_line] if late_words else [k1_line, wq_line]
         if count:                                            # (counting plans: marked (candidate, slice) pairs of this call)
             L += [f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc", dpp8, or_shi, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2],
                   add_o, xor_c, dpp(M, 1)]
@@ -869,7 +872,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
     ]) + [
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
-        "s_nop 0",                                           # (round 3 cleared the next slice's word halves in these two gaps; pk_step's
+        slo_line if late_words else "s_nop 0",               # (round 3 cleared the next slice's word halves in these two gaps; pk_step's
                                                              # acc_first makes that unnecessary)
         dpp(K2, 2),
         "s_nop 0",
