@@ -291,7 +291,8 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         # ONE instruction at steps 0 and 10, round 4)
         None if acc_first else (f"v_lshl_or_b32 {acc}, {acc}, 3, {T}" if cheap else f"v_lshl_add_u32 {acc}, {acc}, 3, {T}"),
         f"v_perm_b32 {D}, %[dqhi], %[dqlo], {D}",
-        f"v_sub_u32 {acc}, {T if acc_first else acc}, {SN}",
+        # (step 0's is tagged as a filler: it takes the wait state behind step 1's v_dot2 pair, which has no rank term to hold yet)
+        f"v_sub_u32 {acc}, {T if acc_first else acc}, {SN}" + (N.get("fill", "") if acc_first and i == 0 else ""),
     ] + ([
         f"v_xor_b32 {D}, {D}, {SN}",
         f"v_sub_u32 {D}, {D}, {SN}",                        # dequantised
@@ -809,8 +810,9 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
         if cheap:                                                                  # marked lanes (cheap_quotient_note): the sign
             body.append(f"v_or_b32 {CH_W}, {N['acca']}, {N['accb']}" + FILL)       # bit of a slice-word half (pk_step)
             body.append(f"v_cmp_gt_i32 vcc, 0, {CH_W}" + FILL)
-        if pen:   # total rank = err^2 sum + penalty sum (both < 2^31: no carry); scheduled, so the v_dot2 wait states hold
-            body.append(f"v_add_u32 {ELO}, {ELO}, {N['pen']}")
+        # (penalty form: total rank = err^2 sum + penalty sum, both < 2^31: no carry -- added in the election, behind the three
+        # instructions that stand between the rank's last v_dot2 and its first reader anyway; inside the scheduled body it had
+        # nothing to wait behind but three s_nop)
         body, b2b = schedule(body)
     if verbose:
         print(f"block body (speculative{', cheap' if cheap else ''}{', penalty' if pen else ''}{', lds' if ldsq else ''}): "
@@ -852,7 +854,10 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
         wq_line = f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc"   # ... and if that wins, the slice is abandoned
         # (the rank's last writer is a v_dot2 / the penalty form's v_add: three instructions stand between it and k1_line --
         # the marks' v_cmp, the second key, and with late_words wq_line)
-        L += [wq_line, k1_line, shi_line] if late_words else [k1_line, wq_line]
+        if pen:   # (the sum goes to the election's copy: a v_dot2's result may be READ three instructions later, not overwritten)
+            k1_line = f"v_cndmask_b32 {K1}, {K1}, {BOUND_IN}, vcc"
+        pen_sum = [f"v_add_u32 {K1}, {ELO}, {N['pen']}"] if pen else []
+        L += [wq_line] + pen_sum + [k1_line, shi_line] if late_words else pen_sum + [k1_line, wq_line]
         if count:                                            # (counting plans: marked (candidate, slice) pairs of this call)
             L += [f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc", dpp8, or_shi, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2],
                   add_o, xor_c, dpp(M, 1)]
