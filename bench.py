@@ -378,27 +378,29 @@ def main_abi_multi(args):
     import qoaudio_amd as q
     from qoaudio_amd import batch, synth
     world = args.gpus
-    if torch.cuda.device_count() < world:
+    dup = bool(args.duplicate_devices)  # all shards on device 0 (the C ABI's test mode): the N-shard control flow on a 1-GPU box
+    if torch.cuda.device_count() < world and not dup:
         print(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
+    dev_of = (lambda i: 0) if dup else (lambda i: i)
     n_clips, ch = args.clips, args.channels
     samples = args.frames * 5120
     desc = q.QoaDesc(ch, args.rate, samples)
     per_pcm, per_enc = samples * ch, q.encoded_size(ch, samples)
-    pcms = [synth.make_clips(n_clips, samples, ch, args.rate, device=f"cuda:{i}", first_index=i * n_clips) for i in range(world)]
+    pcms = [synth.make_clips(n_clips, samples, ch, args.rate, device=f"cuda:{dev_of(i)}", first_index=i * n_clips) for i in range(world)]
     clips = [(k * per_pcm, (i * n_clips + k) * per_enc, desc) for i in range(world) for k in range(n_clips)]
     out = torch.empty((world * n_clips, per_enc), dtype=torch.uint8, device="cuda:0")
-    multi = batch.MultiGpu(list(range(world)))
+    multi = batch.MultiGpu([dev_of(i) for i in range(world)], allow_duplicate_devices=dup)
     flat = [p.view(-1) for p in pcms]
     for _ in range(args.warmup):
         multi.encode(flat, clips, out.view(-1), args.chunk_frames)
     for i in range(world):
-        torch.cuda.synchronize(i)
+        torch.cuda.synchronize(dev_of(i))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         multi.encode(flat, clips, out.view(-1), args.chunk_frames)
     for i in range(world):
-        torch.cuda.synchronize(i)
+        torch.cuda.synchronize(dev_of(i))
     elapsed_ms = (time.perf_counter() - t0) * 1e3
     total_samples = world * n_clips * samples * ch
     ms = elapsed_ms / max(args.steps, 1)
@@ -423,7 +425,7 @@ def main_abi_multi(args):
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "per device, over the wall time of the whole pipelined call (kernels of all time slices + "
                              "staging copies), not a kernel duration"},
-        "multi_gpu_path": "c-abi", "gathered_bytes": int(out.numel()), "gathered_shards_bit_exact_vs_oracle": bool(ok),
+        "multi_gpu_path": "c-abi" + (" (ALL SHARDS ON DEVICE 0: control-flow test mode, not a scaling figure)" if dup else ""), "gathered_bytes": int(out.numel()), "gathered_shards_bit_exact_vs_oracle": bool(ok),
         "bit_exact_vs_oracle": bool(ok),
     }
     print(json.dumps(result))
@@ -446,6 +448,9 @@ def main():
                     help="N > 1 through the C ABI's one-process form (qoa_multi_*: one host thread + pipeline per device, "
                          "peer copies to device 0) instead of one torch.distributed rank per GPU")
     ap.add_argument("--chunk-frames", type=int, default=8, help="--abi-multi: frames per time slice of the device pipelines")
+    ap.add_argument("--duplicate-devices", action="store_true",
+                    help="--abi-multi: put every shard on device 0 (QOA_MULTI_ALLOW_DUPLICATE_DEVICES): times the N-shard control "
+                         "flow, staging and copy path on a 1-GPU box; NOT a scaling measurement")
     args = ap.parse_args()
 
     if args.abi_multi:

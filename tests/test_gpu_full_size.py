@@ -71,3 +71,39 @@ def test_config5_full_length_streaming(gpu, oracle):
     state = enc.lms_state().reshape(ch, 8)
     for c, (hist, weights) in enumerate(ref.lms_state()):
         assert list(state[c, :4]) == hist and list(state[c, 4:]) == weights
+
+
+@pytest.mark.parametrize("channels", [3, 5, 6, 7])
+def test_full_chip_decode_of_channel_counts_that_do_not_divide_a_wavefront(gpu, oracle, channels):
+    """3 / 5 / 6 / 7 channels through K2u's four-wavefront workgroups (>= 1024 wavefronts: the small tests above take its
+    one-wavefront form): mirror lanes, 4-row staging units with spare room per load instruction, masked last store group,
+    XCD-contiguous block order, partial last wavefront.  Every clip against the general kernel K2 (the same plan into a PCM
+    base 2 bytes off the dword grid), 24 clips spread over the batch against the oracle, every frame header verified."""
+    from qoaudio_amd import batch, synth
+    fpw = 64 // channels
+    frames = 16
+    n_clips = (1024 * fpw + 7 * frames) // frames + 1          # a little over 1024 wavefronts, and no multiple of fpw frames
+    assert (n_clips * frames + fpw - 1) // fpw >= 1024 and (n_clips * frames) % fpw != 0
+    samples = frames * 5120
+    distinct = 48
+    base = synth.make_clips(distinct, samples, channels, 48000, device="cuda", first_index=777)
+    pcm = base.repeat(((n_clips + distinct - 1) // distinct, 1, 1))[:n_clips].contiguous()
+    desc = gpu.QoaDesc(channels, 48000, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
+    enc = torch.empty((n_clips, per_enc), dtype=torch.uint8, device="cuda")
+    batch.EncodePlan(clips).run(pcm, enc)
+    dplan = batch.DecodePlan.from_clips(clips)
+    buf = torch.full((n_clips * per_pcm + 8,), 4321, dtype=torch.int16, device="cuda")
+    fast = buf[:n_clips * per_pcm]
+    dplan.run(enc, fast)
+    assert dplan.mismatches() == 0
+    fast = fast.clone()
+    slow = buf[1:1 + n_clips * per_pcm]                        # 2 bytes off the dword grid: the general kernel
+    dplan.run(enc, slow)
+    assert dplan.mismatches() == 0
+    assert torch.equal(fast, slow)
+    host = fast.view(n_clips, per_pcm).cpu().numpy()
+    host_enc = enc.cpu().numpy()
+    for i in np.linspace(0, n_clips - 1, 24).astype(int):
+        _, _, want = oracle.decode_all(host_enc[i].tobytes())
+        assert np.array_equal(host[i], want), (channels, int(i))

@@ -805,8 +805,7 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
         else:
             body += [f"v_pk_sub_i16 {E}, v{SPK0 + 9}, {N['R'][0]} clamp" + FILL,   # the last error pair (spec_rank_pair)
                      f"v_dot2_i32_i16 {ELO}, {E}, {E}, {ELO} clamp" + FILL]
-        if not cheap:                                                              # (the cheap forms switch in an election gap)
-            body.append(f"v_xor_b32 {CANDC}, %[pp], {CANDC}" + FILL)              # the other slot buffer: the entry state stays put
+        # (the switch to the other slot buffer -- the entry state stays put -- sits in a wait-state gap of the election)
         if cheap:                                                                  # marked lanes (cheap_quotient_note): the sign
             body.append(f"v_or_b32 {CH_W}, {N['acca']}, {N['accb']}" + FILL)       # bit of a slice-word half (pk_step)
             body.append(f"v_cmp_gt_i32 vcc, 0, {CH_W}" + FILL)
@@ -823,65 +822,57 @@ def pk_block_spec(N, verbose, ldsq, cheap, pen, stamps, count, wide, G):
     L += body
     if stamps:
         L += ["s_memtime s[88:89]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s92, s88, s86", "s_add_u32 s90, s90, s92"]
-    if ldsq:
-        L.append(f"v_xor_b32 {CANDC}, %[pp], {CANDC}")
     # ---- election, exchange, the one exit test ----
     # ELO's last writer is a v_dot2 (or the penalty form's v_add): three instructions go in front of its first reader
     WQr = WQ if cheap else ("%[winq]" if not pen else LIMV)
     if wide:   # the full form's keys: rank < 2^37 -> rank >> 5, then rank[6:0] : |err0| : sf << 5
-        L += [
+        key_lines = [
             f"v_alignbit_b32 {K1}, v83, {ELO}, 5",
             f"v_lshlrev_b32 {K2}, 25, {ELO}",
             f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
             f"v_or_b32 {K2}, %[sf4], {K2}",
         ]
     else:
-        L.append(f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]")   # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
-    # cheap forms without the marked-pair count: the slice word's halves are formed in wait-state gaps (the high half behind
-    # the rank's v_cndmask, the low half in the second reduction) instead of in slots of their own
-    late_words = cheap and not count
+        key_lines = [f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, %[sf4]"]   # second key |err0| : sf << 5 (slots are 32 bytes apart, %[mf0] = 0x1e0)
+    # Both reductions are chains of four DPP reads, each of which needs two instructions between it and the VALU write of its
+    # source; a v_dot2's result (the rank) needs three before it is read.  The gaps hold the election's own bookkeeping --
+    # the keys, the slice word's halves, tile / out-tile cursors, the next slice's three sample reads, the switch to the other
+    # slot buffer, the exactness test of the saturating rank -- so that (but for one s_nop in the forms with a 32-bit rank, and
+    # the statement of counting plans, which keeps round 3's order) nothing of it takes an issue slot of its own.
     shi_line, slo_line = f"v_lshrrev_b32 {SHI}, 2, {N['acca']}", f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}"
-    if not late_words:
-        L += [shi_line, slo_line]
-    # First reduction: M = the row's best rank.  A DPP read needs two instructions between it and the VALU write of its
-    # source: the gaps hold the election's own bookkeeping -- slice-word head, tile / out-tile cursors, the next slice's three
-    # sample reads, the switch to the other slot buffer.
     or_shi, add_t, add_o = f"v_or_b32 {SHI}, %[sfsh], {SHI}", f"v_add_u32 {TCUR}, 48, {TCUR}", f"v_add_u32 {OCUR}, 8, {OCUR}"
     xor_c = f"v_xor_b32 {CANDC}, %[pp], {CANDC}"             # the other slot buffer: the entry state stays put
     dpp8 = f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf"
+    mov_p = f"v_mov_b32 {PADDR}, {ADDR}"                     # the slot that holds this slice's entry state (read if it is abandoned)
+    s_add = "s_add_u32 %[done], %[done], 1"
+    gap_a = [f"v_cmp_le_u32 vcc, s94, {M}",                  # is the best rank its true rank?  (see spec_rank_pair)
+             f"v_cndmask_b32 {LQ}, {LIMV if pen else '%[limq]'}, {CH_BIG}, vcc"]
+    gap_b, gap_c = [s_add, slo_line], ["s_nop 0", mov_p]
     if cheap:
         k1_line = f"v_cndmask_b32 {K1}, {ELO}, {BOUND_IN}, vcc"   # a marked candidate's rank: what it provably costs (real ranks count from 1)
         wq_line = f"v_cndmask_b32 {WQ}, {LIMV if pen else '%[winq]'}, {CH_BIG}, vcc"   # ... and if that wins, the slice is abandoned
-        # (the rank's last writer is a v_dot2 / the penalty form's v_add: three instructions stand between it and k1_line --
-        # the marks' v_cmp, the second key, and with late_words wq_line)
         if pen:   # (the sum goes to the election's copy: a v_dot2's result may be READ three instructions later, not overwritten)
             k1_line = f"v_cndmask_b32 {K1}, {K1}, {BOUND_IN}, vcc"
-        pen_sum = [f"v_add_u32 {K1}, {ELO}, {N['pen']}"] if pen else []
-        L += [wq_line] + pen_sum + [k1_line, shi_line] if late_words else pen_sum + [k1_line, wq_line]
+        pen_sum = [f"v_add_u32 {K1}, {ELO}, {N['pen']}"] if pen else []   # total rank = err^2 sum + penalty sum (both < 2^31)
         if count:                                            # (counting plans: marked (candidate, slice) pairs of this call)
-            L += [f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc", dpp8, or_shi, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2],
-                  add_o, xor_c, dpp(M, 1)]
-        else:
-            L += [or_shi, dpp8, add_t, reads[0], dpp(M, 4), reads[1], reads[2], dpp(M, 2), add_o, xor_c, dpp(M, 1)]
-    else:
-        L += [or_shi, dpp8, add_o, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2], "s_nop 0", dpp(M, 1)]
+            L += key_lines + [shi_line, slo_line] + pen_sum + [k1_line, wq_line, f"v_addc_co_u32 {MK}, vcc, 0, {MK}, vcc", dpp8,
+                              or_shi, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2], add_o, xor_c, dpp(M, 1)]
+            gap_b = [s_add, "s_nop 0"]
+        else:   # (the rank's last v_dot2, then: the marks' v_cmp, the second key, wq_line -- three -- and its first reader)
+            L += key_lines + [wq_line] + pen_sum + [k1_line, shi_line, or_shi, dpp8, add_t, reads[0], dpp(M, 4), reads[1], reads[2],
+                              dpp(M, 2), add_o, xor_c, dpp(M, 1)]
+    elif wide:  # (the rank is a v_mad_i64's: no v_dot2 wait states; its true rank, so no exactness test -- the gap takes two reads)
+        L += key_lines[:3] + [dpp8, key_lines[3], shi_line, dpp(M, 4), or_shi, add_t, dpp(M, 2), reads[0], xor_c, dpp(M, 1)]
+        gap_a, gap_c = [reads[1], reads[2]], [add_o, mov_p]
+    else:       # exact quotient, 32-bit saturating rank (registers or LDS tables): the three behind the v_dot2 are key, high half, head
+        L += key_lines + [shi_line, or_shi, dpp8, add_o, add_t, dpp(M, 4), reads[0], reads[1], dpp(M, 2), reads[2], xor_c, dpp(M, 1)]
     L += [
         f"v_cmp_eq_u32 vcc, {K1}, {M}",
         f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
         f"ds_write_b128 {CANDC}, v[84:87]",
         f"ds_write_b128 {CANDC}, {SLOT2} offset:16",
         dpp(K2, 8),
-    ] + (["s_nop 1"] if wide else [                          # (the wide form's rank is its true rank)
-        f"v_cmp_le_u32 vcc, s94, {M}",                       # is the best rank its true rank?  (see spec_rank_pair)
-        f"v_cndmask_b32 {LQ}, {LIMV if pen else '%[limq]'}, {CH_BIG}, vcc",
-    ]) + [
-        dpp(K2, 4),
-        "s_add_u32 %[done], %[done], 1",
-        slo_line if late_words else "s_nop 0",               # (round 3 cleared the next slice's word halves in these two gaps; pk_step's
-                                                             # acc_first makes that unnecessary)
-        dpp(K2, 2),
-        "s_nop 0",
-        f"v_mov_b32 {PADDR}, {ADDR}",                        # the slot that holds this slice's entry state (read if it is abandoned)
+    ] + gap_a + [dpp(K2, 4)] + gap_b + [dpp(K2, 2)] + gap_c + [
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, {CANDC}",          # the winner's slot
         f"ds_read_b128 v[84:87], {ADDR}",
