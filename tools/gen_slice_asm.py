@@ -122,36 +122,35 @@ def b32_block():
     L += unpack_samples()
     for i in range(20):
         L += step(i, N)
+    # (round 4: keys, slice-word halves, the candidates' state writes, sample reads and cursors all sit in the wait-state gaps of
+    # the two DPP reductions -- two instructions between a DPP read and the VALU write of its source; one s_nop is left)
     L += [
         f"v_mad_u64_u32 {N['e']}, vcc, {N['pen']}, 1, {N['e']}",   # total rank = sum err^2 + sum penalty^2
-        "ds_write_b128 %[cand], v[84:87]",
-        "ds_write_b128 %[cand], v[88:91] offset:16",
         f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
         f"v_lshlrev_b32 {K2}, 25, {ELO}",
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
-        f"v_or_b32 {K2}, %[sf4], {K2}",
         f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
+        f"v_or_b32 {K2}, %[sf4], {K2}",
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
-        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
         dpp(M, 4),
         f"v_or_b32 {SHI}, %[sfsh], {SHI}",
         f"v_add_u32 {TCUR}, 48, {TCUR}",
         dpp(M, 2),
         reads[0],
-        reads[1],
+        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
         dpp(M, 1),
         f"v_cmp_eq_u32 vcc, {K1}, {M}",
         f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
-        reads[2],
-        f"v_add_u32 {OCUR}, 8, {OCUR}",
+        "ds_write_b128 %[cand], v[84:87]",
+        "ds_write_b128 %[cand], v[88:91] offset:16",
         dpp(K2, 8),
-        "s_add_u32 %[done], %[done], 1",
-        "s_cmp_lt_u32 %[done], %[n]",
+        reads[1],
+        reads[2],
         dpp(K2, 4),
-        "s_nop 0",
-        "s_nop 0",
+        f"v_add_u32 {OCUR}, 8, {OCUR}",
+        "s_add_u32 %[done], %[done], 1",
         dpp(K2, 2),
-        "s_nop 0",
+        "s_cmp_lt_u32 %[done], %[n]",
         "s_nop 0",
         dpp(K2, 1),
         f"v_bfi_b32 {ADDR}, %[mf0], {K2}, %[cand]",          # the winner's slot
@@ -689,28 +688,27 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, coun
         "s_cbranch_vccnz Lqoa_declined_%=",
         # keys of the full form: rank < 2^37 -> rank >> 5, then rank[7:0] : |err0| : sf << 4
         # (slots are 32 bytes apart: %[sf4] = sf << 5, %[mf0] = 0x1e0; the second key keeps rank[6:0] : |err0| : sf << 5)
-        f"ds_write_b128 {cand}, v[84:87]",
+        # (round 4: the last key instruction, the slice word's halves and the candidates' state write sit in DPP gaps too)
         f"v_alignbit_b32 {K1}, {EHI}, {ELO}, 5",
         f"v_lshlrev_b32 {K2}, 25, {ELO}",
         f"v_lshl_or_b32 {K2}, {N['aerr0']}, 9, {K2}",
-        f"v_or_b32 {K2}, %[sf4], {K2}",
         f"v_min_u32_dpp {M}, {K1}, {K1} row_ror:8 row_mask:0xf bank_mask:0xf",
+        f"v_or_b32 {K2}, %[sf4], {K2}",
         f"v_lshrrev_b32 {SHI}, 2, {N['acca']}",
-        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
         dpp(M, 4),
         f"v_or_b32 {SHI}, %[sfsh], {SHI}",
         f"v_add_u32 {TCUR}, 48, {TCUR}",
         dpp(M, 2),
         reads[0],
-        reads[1],
+        f"v_lshl_or_b32 {SLO}, {N['acca']}, 30, {N['accb']}",
         dpp(M, 1),
         f"v_cmp_eq_u32 vcc, {K1}, {M}",
         f"v_cndmask_b32 {K2}, -1, {K2}, vcc",
+        f"ds_write_b128 {cand}, v[84:87]",
+        reads[1],
+        dpp(K2, 8),
         reads[2],
         f"v_add_u32 {OCUR}, 8, {OCUR}",
-        dpp(K2, 8),
-        "s_nop 0",
-        "s_nop 0",
         dpp(K2, 4),
         "s_add_u32 %[done], %[done], 1",
         "s_cmp_lt_u32 %[done], %[n]",
