@@ -811,7 +811,16 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                         if constexpr (valid == FPS) {
                             typedef __attribute__((address_space(1))) u4_unaligned *gptr_t;
                             if constexpr (kStreamed) __builtin_nontemporal_store(vv[o][ln - l0], (gptr_t)(out_ptr[o] + ln * LNB));
+#ifdef QOA_K2U_OFFGRID_POLICY // (tools/k2lab: cache-policy bits of the off-grid flush's stores, e.g. "sc1" or "sc0 sc1")
+                            else {
+                                const unsigned long long a_ = out_ptr[o] + (unsigned)(ln * LNB / 4096 * 4096);
+                                const u4_unaligned v_ = vv[o][ln - l0];
+                                asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " QOA_K2U_OFFGRID_POLICY
+                                             : : "v"(a_), "v"(v_), "n"(ln * LNB % 4096) : "memory");
+                            }
+#else
                             else *(gptr_t)(out_ptr[o] + ln * LNB) = vv[o][ln - l0];
+#endif
                         } else {
                             // the last role group of a frame count that is no multiple of 8: the same store under a lane mask
                             // (always issued -- the vmcnt bookkeeping of the slice loads counts it -- with the idle octets off)
