@@ -398,8 +398,8 @@ __device__ __forceinline__ unsigned run_block_wide(unsigned tile_addr, unsigned 
 
 // The penalty form (QOA_BLOCK_PEN_ASM_TEXT, tools/gen_slice_asm.py: pk_block(pen=True)): cheap-quotient steps WITH the penalty
 // arithmetic on every step; the rank is err^2 + penalty as the full form's, nothing about the penalty is speculated.  What
-// the block loop runs where the speculative forms miss (winners that carry a penalty: tonal passages) -- 27 instead of the
-// full form's 35 instructions per step.  Declines (done < n, entry state restored) like run_block_spec<true> (marked
+// the block loop runs where the speculative forms miss (winners that carry a penalty: tonal passages) -- 26 instead of the
+// full form's 35 instructions per step (the penalty's square is taken two steps at a time).  Declines (done < n, entry state restored) like run_block_spec<true> (marked
 // candidate not provably a loser, rank not provably exact) and like run_block_pk (a candidate's weight energy left the
 // packed window: penalty sum >= kPkPenLimit).
 __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
@@ -414,7 +414,8 @@ __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned c
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
                    [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
                    [selb] "v"(k.selbase), [hi] "v"(k.hi), [limitv] "v"(kPkPenLimit), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
-                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
+                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp),
+                   [hiw] "s"(0x07060302u) // v_perm selector: the high words of two energies side by side (pk_step, penalty form)
                  : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
                    "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
                    "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",

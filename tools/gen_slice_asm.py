@@ -245,14 +245,13 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         slot_a,
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",  # (+-1, +-1) for B_n
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
-        f"v_ashrrev_i32 {PT}, 18, {Q}" if pen_full else None,
+        f"v_ashrrev_i32 {PT}, 18, {Q}" if pen_full and not pen_steps else None,
         sub_t,
         slot_b,
-        f"v_max_i32 {PT}, 0, {PT}" if pen_full else None,   # penalty
+        f"v_max_i32 {PT}, 0, {PT}" if pen_full and not pen_steps else None,   # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1" if not cheap else f"v_ashrrev_i32 {SN}, 31, {T}",
-        ((f"v_mul_i32_i24 {pen}, {PT}, {PT}" if pen_steps and i == 0 else   # (penalty form: the first term starts the sum)
-          f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}") if pen_full else None),
+        f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}" if pen_full and not pen_steps else None,
         (None if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
         f"v_ashrrev_i32 {U}, 16, {U}" if not cheap else None,
     ] + ([
@@ -314,6 +313,19 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_cvt_pk_i16_i32 {Bn}, {RC[(i + 1) % 2]}, {rc}",
     ])
     L = [l for l in L if l is not None]
+    if pen_steps and i % 2:
+        # Penalty form, two steps at a time (round 4): the steps' energies minus the limit sit in Q of the even step (main
+        # temporaries) and of this one; their high words are (E - limit) >> 16 as i16, two more arithmetic shifts make the
+        # reference's (E >> 18) - 0x8ff, and max(0, .)^2 of both goes into the sum with one v_dot2: 4 instructions per step pair
+        # where v_ashrrev + v_max + v_mad per step were 6.  Each penalty is < 2^13, the sum of 20 squares < 2^31 as before.
+        q_even = f"v{PK_Q}"
+        k = max(j for j, l in enumerate(L) if l.startswith("v_dot2_i32_i16 " + Q + ",")) + 1
+        L[k:k] = [
+            f"v_perm_b32 {PT}, {Q}, {q_even}, %[hiw]",
+            f"v_pk_ashrrev_i16 {PT}, 2, {PT} op_sel_hi:[0,1]",
+            f"v_pk_max_i16 {PT}, {PT}, 0 op_sel_hi:[1,0]",
+            f"v_dot2_i32_i16 {pen}, {PT}, {PT}, {0 if i == 1 else pen}",
+        ]
     if not spec:
         assert len(L) == 35
         if i == 1:  # |err| of the first sample, right after slot_a produced it
@@ -325,7 +337,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
     else:
-        assert len(L) == (22 if cheap else 26) + ((2 if i == 0 else 3) if check else 0) + (5 if pen_steps else 0) + (2 if i % 2 == 0 else 0) - (
+        assert len(L) == (22 if cheap else 26) + ((2 if i == 0 else 3) if check else 0) + ((6 if i % 2 else 2) if pen_steps else 0) + (2 if i % 2 == 0 else 0) - (
             2 if i == 0 and N.get("acc_cleared") else 0) - (1 if acc_first else 0)
         if i == 2:
             k = L.index(slot_b) + 1
@@ -631,7 +643,7 @@ def pk_block(verbose=False, spec=False, ldsq=False, cheap=False, pen=False, coun
     therefore double-buffered (%[pp] = byte distance) so that the entry state is still there for a late exit.
 
     pen=True (with spec and cheap) is the PENALTY form: the cheap-quotient speculative step plus the full form's penalty
-    arithmetic on every step (27 instructions + the rank pair every second step).  Nothing is speculated about the
+    arithmetic on every step (26 instructions + the rank pair every second step).  Nothing is speculated about the
     penalty: the rank the election sees is the saturating err^2 sum plus the penalty sum, exact whenever it is below
     32767^2 (then so is its err^2 part); the exactness of the i16 arithmetic is the full form's test, penalty sum <
     %[limit] for all 64 candidates.  No energy sampling, no winner test after the election.  It is what the block loop
@@ -933,7 +945,7 @@ def render(verbose=False):
            + emit("QOA_BLOCK_CHEAP_ASM_TEXT", blk_cheap) + "\n"
            + "// QOA_BLOCK_CHEAP_COUNT_ASM_TEXT: the same with a count of the marked (candidate, slice) pairs (plans with counters).\n"
            + emit("QOA_BLOCK_CHEAP_COUNT_ASM_TEXT", blk_cheap_count) + "\n"
-           + "// QOA_BLOCK_PEN_ASM_TEXT: the cheap-quotient loop WITH the penalty arithmetic on every step (27/step): what the\n"
+           + "// QOA_BLOCK_PEN_ASM_TEXT: the cheap-quotient loop WITH the penalty arithmetic on every step (26/step): what the\n"
            + "//   block loop falls back to where the speculative forms miss (winners that carry a penalty), before the full form.\n"
            + emit("QOA_BLOCK_PEN_ASM_TEXT", blk_pen) + "\n"
            + "// QOA_BLOCK_WIDE_ASM_TEXT: exact-quotient speculative steps with the true 64-bit rank and the weight energy sampled at\n"
