@@ -283,7 +283,8 @@ __device__ __forceinline__ unsigned run_block_pk(unsigned tile_addr, unsigned ca
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy),
                    [sf4] "v"((unsigned)sf << 5), [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo),
                    [dqhi] "v"(k.dq_hi), [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101),
-                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0x1e0)
+                   [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [limit] "s"(kPkPenLimit), [mf0] "s"(0x1e0),
+                   [hiw] "s"(0x07060302u) // (the penalties of two steps side by side: pk_step, pair_pen)
                  : "vcc", "scc", "memory", "s95", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91",
                    "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
                    "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
@@ -425,7 +426,8 @@ __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned c
     return done;
 }
 
-// `n` consecutive full slices on the 32-bit step in ONE statement (QOA_BLOCK_32_ASM_TEXT, tools/gen_slice_asm.py: b32_block):
+// `n` consecutive full slices on the 32-bit step (38.5 instructions: the penalty is squared two steps at a time) in ONE statement
+// (QOA_BLOCK_32_ASM_TEXT, tools/gen_slice_asm.py: b32_block, step_pair_pen):
 // full i32 weights, so it cannot decline -- the block loop's last resort for wavefronts with a chain whose state, or whose
 // losing candidates, leave the packed forms' window slice after slice.  Election and state exchange as in run_block_pk, with
 // both halves of the 32-byte slot (history, weights).
@@ -445,7 +447,7 @@ __device__ __forceinline__ void run_block_32(unsigned tile_addr, unsigned cand, 
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
                    [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
                    [selb] "v"(k.selbase), [hi] "v"(k.hi), [rnd] "s"(1 << 15), [c101] "s"(0x0101), [lo] "s"(-32768), [n] "s"(n),
-                   [mf0] "s"(0x1e0)
+                   [mf0] "s"(0x1e0), [hiw] "s"(0x07060302u), [c8ff2] "s"(0x08ff08ffu) // (the pair-wise penalty: step_pair_pen)
                  : "vcc", "scc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v92",
                    "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
                    "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",

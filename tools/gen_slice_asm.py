@@ -43,6 +43,8 @@ def step(i, N=STEP_OPERANDS):
     smp = f"v{SMP0 + i}"
     acc = N["acca"] if i < 10 else N["accb"]
     p, q = f"v[{P}:{P + 1}]", f"v[{Q}:{Q + 1}]"
+    if N.get("pair_pen"):
+        return step_pair_pen(i, N, h, s, w, smp, acc)
     L = [
         f"v_mul_lo_u32 v{P}, {w[0]}, {h[0]}",
         f"v_mul_lo_u32 v{Q}, {w[0]}, {w[0]}",
@@ -95,6 +97,70 @@ def step(i, N=STEP_OPERANDS):
     return L
 
 
+def step_pair_pen(i, N, h, s, w, smp, acc):
+    """The 32-bit step of the block loop with the weights penalty squared two steps at a time (round 4): the energy of an even
+    step stays in v118, the odd step's goes to v92; behind it v_perm_b32 puts their high words side by side ((E >> 16) as
+    i16), v_pk_ashrrev_i16 .., 2 makes E >> 18 of each, v_pk_max_i16 / v_pk_sub_i16 with 0x08ff08ff the reference's
+    max(E >> 18, 0x8ff) - 0x8ff (the energy is NOT biased beforehand as in the packed forms: this form must reproduce the
+    reference for every state, including energies that wrap the i32), and one v_dot2_i32_i16 squares and adds both: 5
+    instructions per step pair where shift, max, add and v_mad per step were 8 -- 38.5 instead of 41 per step.  The five are
+    spread over the odd step so that no packed result is read by the instruction right behind it."""
+    QE, QO, PP = 118, 92, "v94"
+    Qr = QO if i % 2 else QE
+    p, q = f"v[{P}:{P + 1}]", f"v[{Qr}:{Qr + 1}]"
+    odd = i % 2 == 1
+    pen = N["pen"]
+    L = [
+        f"v_mul_lo_u32 v{P}, {w[0]}, {h[0]}",
+        f"v_mul_lo_u32 v{Qr}, {w[0]}, {w[0]}",
+        f"v_mad_u64_u32 {p}, vcc, {w[1]}, {h[1]}, {p}",
+        f"v_mad_u64_u32 {q}, vcc, {w[1]}, {w[1]}, {q}",
+        f"v_mad_u64_u32 {p}, vcc, {w[2]}, {h[2]}, {p}",
+        f"v_mad_u64_u32 {q}, vcc, {w[2]}, {w[2]}, {q}",
+        f"v_mad_u64_u32 {p}, vcc, {w[3]}, {h[3]}, {p}",
+        f"v_mad_u64_u32 {q}, vcc, {w[3]}, {w[3]}, {q}",
+        f"v_ashrrev_i32 v{P}, 13, v{P}",
+        f"v_perm_b32 {PP}, v{QO}, v{QE}, %[hiw]" if odd else None,
+        f"v_sub_u32 v{T}, {smp}, v{P}",
+        f"v_pk_ashrrev_i16 {PP}, 2, {PP} op_sel_hi:[0,1]" if odd else None,
+        f"v_mad_i32_i24 v{U}, v{T}, %[recip], %[rnd]",
+        f"v_pk_max_i16 {PP}, {PP}, %[c8ff2]" if odd else None,
+        f"v_med3_i32 v{T}, v{T}, -1, 1",
+        f"v_pk_sub_i16 {PP}, {PP}, %[c8ff2]" if odd else None,
+        f"v_ashrrev_i32 v{U}, 16, v{U}",
+        f"v_lshl_add_u32 v{SNEG}, v{T}, 1, v{U}",           # n + 2 sgn(residual)
+        f"v_dot2_i32_i16 {pen}, {PP}, {PP}, {0 if i == 1 else pen}" if odd else None,
+        f"v_med3_i32 v{U}, v{U}, v{SNEG}, v{T}",            # scaled = n + sgn(residual) - sgn(n), see cand_step()
+        f"v_sub_u32 v{T}, 0, v{U}",
+        f"v_ashrrev_i32 v{SNEG}, 31, v{U}",
+        f"v_max_i32 v{T}, v{U}, v{T}",
+        f"v_min_i32 v{T}, 7, v{T}",
+        f"v_and_b32 v{T}, 6, v{T}",
+        f"v_mad_u32_u24 v{D}, v{T}, %[c101], %[selb]",
+        f"v_lshl_add_u32 {acc}, {acc}, 3, v{T}",
+        f"v_perm_b32 v{D}, %[dqhi], %[dqlo], v{D}",
+        f"v_sub_u32 {acc}, {acc}, v{SNEG}",
+        f"v_xor_b32 v{D}, v{D}, v{SNEG}",
+        f"v_sub_u32 v{D}, v{D}, v{SNEG}",
+        f"v_add_u32 v{U}, v{D}, v{P}",
+        f"v_ashrrev_i32 v{D}, 4, v{D}",
+        f"v_med3_i32 {h[0]}, v{U}, %[lo], %[hi]",          # reconstructed -> the oldest history slot = new newest
+        f"v_mad_i32_i24 {w[0]}, {s[0]}, v{D}, {w[0]}",
+        f"v_sub_u32 v{T}, {smp}, {h[0]}",                   # err
+        f"v_mad_i32_i24 {w[1]}, {s[1]}, v{D}, {w[1]}",
+        f"v_ashrrev_i32 {s[0]}, 31, {h[0]}",                # sign of the new sample -> the oldest sign slot
+        f"v_mad_i32_i24 {w[2]}, {s[2]}, v{D}, {w[2]}",
+        f"v_mad_i64_i32 {N['e']}, vcc, v{T}, v{T}, {N['e']}",
+        f"v_mad_i32_i24 {w[3]}, {s[3]}, v{D}, {w[3]}",
+        f"v_or_b32 {s[0]}, 1, {s[0]}",
+    ]
+    L = [l for l in L if l is not None]
+    assert len(L) == (42 if odd else 37)
+    if i == 0:  # |err| of the first sample orders the first-sample ranks
+        L += [f"v_sub_u32 v{U}, 0, v{T}", f"v_max_i32 {N['aerr0']}, v{T}, v{U}"]
+    return L
+
+
 def b32_block():
     """Up to %[n] consecutive full slices on the 32-bit step (step(): 41 instructions, full i32 weights -- it cannot decline)
     in one statement: the block loop's last resort for chains whose state, or whose LOSING candidates, leave the i16 window
@@ -102,7 +168,7 @@ def b32_block():
     ds_bpermute + a re-admission test, after a wasted packed attempt: 2,100 issue slots per slice against ~900 here.
     State: v[84:87] history, v[88:91] weights; every candidate parks both halves in its 32-byte LDS slot, the election is the
     full form's (keys rank >> 5, then rank[6:0] : |err0| : sf << 5), all 16 lanes read the winner's slot back."""
-    N = B32_FIXED
+    N = dict(B32_FIXED, pair_pen=True)
     K1, M, K2, ADDR, OADDR = "v116", "v117", "v118", "v72", "v120"   # K1/M/K2 share the dot-product registers (dead by then)
     TCUR, OCUR = "v74", "v75"
     SHI, SLO, ELO, EHI = "v80", "v81", "v82", "v83"
@@ -118,7 +184,7 @@ def b32_block():
     ]
     for j in range(4):
         L += [f"v_ashrrev_i32 v{S0 + j}, 31, {N['h'][j]}", f"v_or_b32 v{S0 + j}, 1, v{S0 + j}"]
-    L += [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['pen']}, 0", f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"]
+    L += [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"]   # (the penalty sum starts with its first term)
     L += unpack_samples()
     for i in range(20):
         L += step(i, N)
@@ -230,6 +296,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     # -- for the stretches where the speculation's premise (a penalty-free winner) does not hold: see pk_block.
     pen_steps = bool(N.get("pen_steps"))
     pen_full = not spec or pen_steps
+    pair_pen = pen_steps or (not spec and bool(N.get("alt")))   # penalties squared two steps at a time (two temporary sets needed)
     check = spec and not pen_steps and (i % 4 == 0 or bool(N.get("wide")))   # (the wide form samples the energy at every step)
     cheap = bool(N.get("cheap"))
     acc_first = bool(N.get("acc_cleared")) and spec and i in (0, 10)
@@ -245,13 +312,13 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         slot_a,
         f"v_or_b32 {SB}, {N.get('one2', '0x10001')}, {SB}",  # (+-1, +-1) for B_n
         f"v_ashrrev_i32 {PR}, 13, {P}",                     # predicted
-        f"v_ashrrev_i32 {PT}, 18, {Q}" if pen_full and not pen_steps else None,
+        f"v_ashrrev_i32 {PT}, 18, {Q}" if pen_full and not pair_pen else None,
         sub_t,
         slot_b,
-        f"v_max_i32 {PT}, 0, {PT}" if pen_full and not pen_steps else None,   # penalty
+        f"v_max_i32 {PT}, 0, {PT}" if pen_full and not pair_pen else None,   # penalty
         f"v_mad_i32_i24 {U}, {T}, %[recip], %[rnd]",
         f"v_med3_i32 {T}, {T}, -1, 1" if not cheap else f"v_ashrrev_i32 {SN}, 31, {T}",
-        f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}" if pen_full and not pen_steps else None,
+        f"v_mad_i32_i24 {pen}, {PT}, {PT}, {pen}" if pen_full and not pair_pen else None,
         (None if i == 0 else f"v_max_i32 {N['qm']}, {N['qm']}, {Q}") if check else None,
         f"v_ashrrev_i32 {U}, 16, {U}" if not cheap else None,
     ] + ([
@@ -313,8 +380,8 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
         f"v_cvt_pk_i16_i32 {Bn}, {RC[(i + 1) % 2]}, {rc}",
     ])
     L = [l for l in L if l is not None]
-    if pen_steps and i % 2:
-        # Penalty form, two steps at a time (round 4): the steps' energies minus the limit sit in Q of the even step (main
+    if pair_pen and i % 2:
+        # Penalty and full form of the block loop, two steps at a time (round 4): the steps' energies minus the limit sit in Q of the even step (main
         # temporaries) and of this one; their high words are (E - limit) >> 16 as i16, two more arithmetic shifts make the
         # reference's (E >> 18) - 0x8ff, and max(0, .)^2 of both goes into the sum with one v_dot2: 4 instructions per step pair
         # where v_ashrrev + v_max + v_mad per step were 6.  Each penalty is < 2^13, the sum of 20 squares < 2^31 as before.
@@ -324,10 +391,10 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
             f"v_perm_b32 {PT}, {Q}, {q_even}, %[hiw]",
             f"v_pk_ashrrev_i16 {PT}, 2, {PT} op_sel_hi:[0,1]",
             f"v_pk_max_i16 {PT}, {PT}, 0 op_sel_hi:[1,0]",
-            f"v_dot2_i32_i16 {pen}, {PT}, {PT}, {0 if i == 1 else pen}",
+            f"v_dot2_i32_i16 {pen}, {PT}, {PT}, {0 if i == 1 and pen_steps else pen}",   # (the full form clears its sum in the election)
         ]
     if not spec:
-        assert len(L) == 35
+        assert len(L) == (35 if not pair_pen else 36 if i % 2 else 32)
         if i == 1:  # |err| of the first sample, right after slot_a produced it
             k = L.index(slot_a) + 1
             L[k:k] = [f"v_sub_u32 {D}, 0, {E}", f"v_max_i32 {N['aerr0']}, {E}, {D}"]
