@@ -103,9 +103,11 @@ def step_pair_pen(i, N, h, s, w, smp, acc):
     i16), v_pk_ashrrev_i16 .., 2 makes E >> 18 of each, v_pk_max_i16 / v_pk_sub_i16 with 0x08ff08ff the reference's
     max(E >> 18, 0x8ff) - 0x8ff (the energy is NOT biased beforehand as in the packed forms: this form must reproduce the
     reference for every state, including energies that wrap the i32), and one v_dot2_i32_i16 squares and adds both: 5
-    instructions per step pair where shift, max, add and v_mad per step were 8 -- 38.5 instead of 41 per step.  The five are
+    instructions per step pair where shift, max, add and v_mad per step were 8; with the sign multiplications below 37.5
+    instead of 41 per step.  The five are
     spread over the odd step so that no packed result is read by the instruction right behind it."""
-    QE, QO, PP = 118, 92, "v94"
+    QE, QO, PP, A1 = 118, 92, "v94", "v95"
+    first = i in (0, 10)
     Qr = QO if i % 2 else QE
     p, q = f"v[{P}:{P + 1}]", f"v[{Qr}:{Qr + 1}]"
     odd = i % 2 == 1
@@ -131,17 +133,18 @@ def step_pair_pen(i, N, h, s, w, smp, acc):
         f"v_lshl_add_u32 v{SNEG}, v{T}, 1, v{U}",           # n + 2 sgn(residual)
         f"v_dot2_i32_i16 {pen}, {PP}, {PP}, {0 if i == 1 else pen}" if odd else None,
         f"v_med3_i32 v{U}, v{U}, v{SNEG}, v{T}",            # scaled = n + sgn(residual) - sgn(n), see cand_step()
-        f"v_sub_u32 v{T}, 0, v{U}",
+        # |scaled| and, further down, the dequantised value's sign as multiplications by a1 = +-1 (as the speculative forms do:
+        # one instruction less than negate + max and xor + subtract)
         f"v_ashrrev_i32 v{SNEG}, 31, v{U}",
-        f"v_max_i32 v{T}, v{U}, v{T}",
+        f"v_or_b32 {A1}, 1, v{SNEG}",
+        f"v_mul_i32_i24 v{T}, v{U}, {A1}",                   # |scaled| (< 2^16)
         f"v_min_i32 v{T}, 7, v{T}",
         f"v_and_b32 v{T}, 6, v{T}",
         f"v_mad_u32_u24 v{D}, v{T}, %[c101], %[selb]",
-        f"v_lshl_add_u32 {acc}, {acc}, 3, v{T}",
+        None if first else f"v_lshl_add_u32 {acc}, {acc}, 3, v{T}",   # (the first code of a slice-word half needs no shift)
         f"v_perm_b32 v{D}, %[dqhi], %[dqlo], v{D}",
-        f"v_sub_u32 {acc}, {acc}, v{SNEG}",
-        f"v_xor_b32 v{D}, v{D}, v{SNEG}",
-        f"v_sub_u32 v{D}, v{D}, v{SNEG}",
+        f"v_sub_u32 {acc}, {('v%d' % T) if first else acc}, v{SNEG}",
+        f"v_mul_i32_i24 v{D}, v{D}, {A1}",                   # dequantised
         f"v_add_u32 v{U}, v{D}, v{P}",
         f"v_ashrrev_i32 v{D}, 4, v{D}",
         f"v_med3_i32 {h[0]}, v{U}, %[lo], %[hi]",          # reconstructed -> the oldest history slot = new newest
@@ -150,12 +153,12 @@ def step_pair_pen(i, N, h, s, w, smp, acc):
         f"v_mad_i32_i24 {w[1]}, {s[1]}, v{D}, {w[1]}",
         f"v_ashrrev_i32 {s[0]}, 31, {h[0]}",                # sign of the new sample -> the oldest sign slot
         f"v_mad_i32_i24 {w[2]}, {s[2]}, v{D}, {w[2]}",
-        f"v_mad_i64_i32 {N['e']}, vcc, v{T}, v{T}, {N['e']}",
+        f"v_mad_i64_i32 {N['e']}, vcc, v{T}, v{T}, {0 if i == 0 else N['e']}",   # (the first term starts the rank)
         f"v_mad_i32_i24 {w[3]}, {s[3]}, v{D}, {w[3]}",
         f"v_or_b32 {s[0]}, 1, {s[0]}",
     ]
     L = [l for l in L if l is not None]
-    assert len(L) == (42 if odd else 37)
+    assert len(L) == (41 if odd else 36) - (1 if first else 0)
     if i == 0:  # |err| of the first sample orders the first-sample ranks
         L += [f"v_sub_u32 v{U}, 0, v{T}", f"v_max_i32 {N['aerr0']}, v{T}, v{U}"]
     return L
@@ -184,7 +187,7 @@ def b32_block():
     ]
     for j in range(4):
         L += [f"v_ashrrev_i32 v{S0 + j}, 31, {N['h'][j]}", f"v_or_b32 v{S0 + j}, 1, v{S0 + j}"]
-    L += [f"v_mov_b64 {N['e']}, 0", f"v_mov_b32 {N['acca']}, 0", f"v_mov_b32 {N['accb']}, 0"]   # (the penalty sum starts with its first term)
+    # (no per-slice clears: the rank, the penalty sum and the slice word's halves all start with their first term)
     L += unpack_samples()
     for i in range(20):
         L += step(i, N)
