@@ -426,7 +426,7 @@ __device__ __forceinline__ unsigned run_block_pen(unsigned tile_addr, unsigned c
     return done;
 }
 
-// `n` consecutive full slices on the 32-bit step (37.5 instructions: the penalty is squared two steps at a time) in ONE statement
+// `n` consecutive full slices on the 32-bit step (38.5 instructions: the penalty is squared two steps at a time) in ONE statement
 // (QOA_BLOCK_32_ASM_TEXT, tools/gen_slice_asm.py: b32_block, step_pair_pen):
 // full i32 weights, so it cannot decline -- the block loop's last resort for wavefronts with a chain whose state, or whose
 // losing candidates, leave the packed forms' window slice after slice.  Election and state exchange as in run_block_pk, with

@@ -103,7 +103,7 @@ def step_pair_pen(i, N, h, s, w, smp, acc):
     i16), v_pk_ashrrev_i16 .., 2 makes E >> 18 of each, v_pk_max_i16 / v_pk_sub_i16 with 0x08ff08ff the reference's
     max(E >> 18, 0x8ff) - 0x8ff (the energy is NOT biased beforehand as in the packed forms: this form must reproduce the
     reference for every state, including energies that wrap the i32), and one v_dot2_i32_i16 squares and adds both: 5
-    instructions per step pair where shift, max, add and v_mad per step were 8; with the sign multiplications below 37.5
+    instructions per step pair where shift, max, add and v_mad per step were 8; with the sign multiplications below 38.5
     instead of 41 per step.  The five are
     spread over the odd step so that no packed result is read by the instruction right behind it."""
     QE, QO, PP, A1 = 118, 92, "v94", "v95"
