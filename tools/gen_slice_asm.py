@@ -300,9 +300,7 @@ def pk_step(i, N=PK_OPERANDS, spec=False):
     pen_steps = bool(N.get("pen_steps"))
     pen_full = not spec or pen_steps
     pair_pen = pen_steps or (not spec and bool(N.get("alt")))   # penalties squared two steps at a time (two temporary sets needed)
-    # (the wide form samples the energy at every step; lab variant "sample5": every 5th step, margins for 4 unsampled steps --
-    # -DQOA_SPEC_UNSAMPLED=4 on the kernel side)
-    check = spec and not pen_steps and (i % (5 if "sample5" in LAB else 4) == 0 or bool(N.get("wide")))
+    check = spec and not pen_steps and (i % 4 == 0 or bool(N.get("wide")))   # (the wide form samples the energy at every step)
     cheap = bool(N.get("cheap"))
     acc_first = bool(N.get("acc_cleared")) and spec and i in (0, 10)
     A1 = CH_A1[i % 2]
