@@ -139,7 +139,7 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_NO_BLOCK32 2048u       /* debug: slices the packed forms cannot take go one by one, not through the 32-bit block loop */
 #define QOA_PLAN_NO_HELPER 4096u        /* debug: no helper wavefronts (K1's two-wavefront workgroups for launches that leave SIMDs idle) */
 #define QOA_PLAN_FORCE_HELPER 8192u     /* debug: helper wavefronts whatever the launch size */
-#define QOA_PLAN_NO_WIDE_FORM 16384u     /* debug: no wide form (64-bit rank, energy sampled at every step: full-scale noise); same bytes */
+#define QOA_PLAN_NO_WIDE_FORM 16384u     /* debug: no wide form (exact quotient with the true 64-bit rank: full-scale noise); same bytes */
 #define QOA_PLAN_COUNTERS 512u         /* count the fast paths' fall-backs (qoa_encode_plan_stats / _counters); without it the */
                                        /* kernel is handed no counter block and executes no atomic at all */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: 4) */
@@ -183,7 +183,7 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
  *   out[5] (wavefront, slice) pairs evaluated on the 32-bit step (block statement, one-slice statement or tail path), out[6] on the one-slice packed statement;
  *   out[7] slices the penalty form (cheap-quotient steps with the penalty arithmetic: the fall-back for speculation
  *          misses) declined and handed on;
- *   out[8] slices the wide form (64-bit rank, weight energy sampled at every step: full-scale noise) declined and handed to the
+ *   out[8] slices the wide form (exact quotient with the true 64-bit rank: full-scale noise) declined and handed to the
  *          full form, out[9] (wavefront, slice) pairs it settled.
  * Entries beyond the last counter read 0. */
 int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n);

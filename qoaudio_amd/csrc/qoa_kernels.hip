@@ -367,16 +367,16 @@ __device__ __forceinline__ unsigned run_block_spec(unsigned tile_addr, unsigned 
 }
 
 // The wide form (QOA_BLOCK_WIDE_ASM_TEXT, tools/gen_slice_asm.py: pk_block(wide=True), round 4): exact-quotient speculative
-// steps with the TRUE 64-bit rank (one error term per step instead of the saturating pair sum) and the weight energy sampled
-// at EVERY step -- 30 instructions per step.  For material whose winners' ranks exceed the saturating rank's exact range
+// steps with the TRUE 64-bit rank (one error term per step instead of the saturating pair sum) -- 28 instructions per step.  For material whose winners' ranks exceed the saturating rank's exact range
 // (32767^2) and whose scalefactor-0/1 candidates wrap without a provable bound, but whose winners carry NO penalty:
 // full-scale noise (tools/k1lab/leaver_study.c: 92 % of its winners' ranks are beyond 32767^2, a candidate is marked in 48 % of
 // its slices with no bound at all, and no winner carries a penalty).  Before, that class ran on the 35-instruction full form.
-// With a sample at every step the two energy tests need no margins for unsampled steps (limq0 / winq0): the margins are what
-// made the 4-step forms miss on noise, whose winners are high scalefactors with large weight steps.  Declines (done < n, entry
-// state restored) when a winner's penalty is not zero or a candidate's energy left the packed window.
+// The energy tests are those of run_block_spec (a sample at every 4th step, spec_limits' margins); until late in round 4 this form
+// sampled at every step (30 per step) on the belief that the margins made noise miss on the other forms -- measured: with the
+// margins it declines 516 of white noise's 2,097,152 wavefront-slices and runs 6 % faster.  Declines (done < n, entry state
+// restored) when a winner's penalty is not provably zero or a candidate's energy may have left the packed window.
 __device__ __forceinline__ unsigned run_block_wide(unsigned tile_addr, unsigned cand, unsigned pp, unsigned outb, unsigned dummy,
-                                                   int sf, const StepConst &k, int limq0, int winq0, unsigned n, PkLms &pk) {
+                                                   int sf, const StepConst &k, int limq, int winq, unsigned n, PkLms &pk) {
     register unsigned w01 asm("v84") = pk.w01;
     register unsigned w23 asm("v85") = pk.w23;
     register unsigned pa asm("v86") = pk.pa;
@@ -386,7 +386,7 @@ __device__ __forceinline__ unsigned run_block_wide(unsigned tile_addr, unsigned 
                  : "+v"(w01), "+v"(w23), "+v"(pa), "+v"(pb), [done] "=&s"(done), [tmp] "=&s"(tmp)
                  : [tile] "v"(tile_addr), [cand] "v"(cand), [outb] "v"(outb), [dummy] "v"(dummy), [sf4] "v"((unsigned)sf << 5),
                    [sfsh] "v"((unsigned)sf << 28), [recip] "v"(k.recip), [dqlo] "v"(k.dq_lo), [dqhi] "v"(k.dq_hi),
-                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq0), [winq] "v"(winq0), [rnd] "s"(1 << 15),
+                   [selb] "v"(k.selbase), [hi] "v"(k.hi), [limq] "v"(limq), [winq] "v"(winq), [rnd] "s"(1 << 15),
                    [c101] "s"(0x0101), [lo] "s"(-32768), [negc] "s"(-(0x8ff << 18)), [n] "s"(n), [mf0] "s"(0x1e0), [pp] "s"(pp)
                  : "vcc", "scc", "memory", "s94", "s95", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
                    "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
@@ -780,8 +780,6 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // material that defeats a form does so for long stretches (tonal passages keep the weights at the penalty threshold for
     // seconds; full-scale noise and clipped material never leave it), an isolated miss costs the rest of its block only.
     unsigned spec_streak = 0, pen_cooldown = 0, pen_streak = 0, pk_cooldown = 0, pk_streak = 0, wide_cooldown = 0, wide_streak = 0;
-    // the wide form's limits: the energy is sampled at every step, no margins (spec_limits)
-    const int limq0 = (int)(kPkEnergyLimit - (0x8ffll << 18)), winq0 = 1 << 18;
     // The steady state: no form sitting out, no streak running, every chain of the wave packed -- then a whole block goes to the
     // cheap-quotient statement behind ONE test (a lone wavefront pays ~25 cycles per branch and the ladder below has a dozen:
     // ~700 cycles per block, 1.6 % of the kernel, measured with tools/k1lab/stamps.py).  ok_blocks = the lane's number of whole
@@ -1018,7 +1016,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     // the penalty form declined (or sits out): ranks beyond the saturating rank's range, marked candidates
                     // without a bound -- noise.  Penalty-free winners assumed, proven per slice (run_block_wide).
                     const unsigned r = run_block_wide(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j, dummy_addr,
-                                                      sf, kc, limq0, winq0, kBlockSlices - j, pk);
+                                                      sf, kc, limq, winq, kBlockSlices - j, pk);
                     const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
                     j += rw;
                     QOA_LAB_FORM(3, rw + (j < kBlockSlices ? 1u : 0u));
