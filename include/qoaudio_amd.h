@@ -111,6 +111,10 @@ int qoa_debug_encode_slice(const int32_t *state /* 8 */, const int16_t *samples,
                            uint64_t *total_rank /* 16 */, uint64_t *first_rank /* 16 */, uint64_t *slices /* 16 */,
                            int32_t *end_states /* 16*8 */);
 
+/* Test hook: the handle's later launches take the step-form switches of qoa_encode_plan_create's flags (QOA_PLAN_* below;
+ * QOA_PLAN_COUNTERS is ignored).  Same bytes by construction -- the fuzz tests compare every form from hostile states. */
+int qoa_debug_encoder_set_plan_flags(qoa_encoder *enc, uint32_t flags);
+
 /* encode_all, src/lib.rs:760-763. */
 int qoa_encode_all(const int16_t *pcm, size_t n_i16, const qoa_desc *desc, uint8_t *out, size_t cap,
                    size_t *written);

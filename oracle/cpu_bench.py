@@ -1,18 +1,28 @@
 """CPU baseline legs of bench.py, run in a process that never touches the GPU.
 
-    python -m oracle.cpu_bench <clips.npy> <sample_rate> <budget_seconds> [--no-all-cores] [--no-digests]
+    python -m oracle.cpu_bench <clips.npy> <sample_rate> <budget_seconds> [--no-all-cores] [--no-decode]
 
 QOA_ORACLE_LIB=liboracle_native.so in the environment times the -march=native build instead (rebuilt first when
 `--rebuild` is given: -march=native must be compiled on the machine it runs on).
 
 TEST INFRASTRUCTURE ONLY (see oracle/README.md).  bench.py copies a bounded sample of the very clips the GPU
-encoded to a .npy file and starts this module as a child process; the child times the oracle's ref_style encoder
-(the reference's algorithm including its rank-sorted early exits, src/lib.rs:516-593) on one thread, then on all
-host cores (one clip per forked worker -- forking is safe here, there is no HIP context in this process), and
-prints one JSON object.  The sha256 of every encoded clip goes back so the parent can compare bytes with the GPU's.
+encoded to a .npy file and starts this module as a child process; the child times
+  * the oracle's ref_style encoder (the reference's algorithm including its rank-sorted early exits,
+    src/lib.rs:516-593) on ONE thread -- what the reference does: it is single-threaded (benches/qoa_benchmarks.rs:17-30);
+  * the oracle's decode_all (the reference's item-by-item iterator drain, src/lib.rs:713-747 over :661-693 and
+    :291-330; the crate's own decode bench is the same loop, benches/qoa_benchmarks.rs:6-15) on the streams the encoder
+    leg just produced, ONE thread;
+  * the encoder on every CPU this process may actually run on, one worker process per CPU, each looping over clips for
+    a fixed time (forking is safe here, there is no HIP context in this process),
+and prints one JSON object.  The sha256 of every encoded clip and of every decoded clip's PCM go back so that the parent
+can compare bytes with the GPU's.
+
+"Every CPU this process may run on" is NOT os.cpu_count(): round 4's line said "cores": 256 for a process confined to
+a dozen (verdict, weak #5).  usable_cpus() = the scheduler affinity mask, capped by the cgroup's CPU quota.
 """
 import hashlib
 import json
+import math
 import multiprocessing as mp
 import os
 import sys
@@ -24,10 +34,93 @@ _CLIPS = None
 _RATE = 0
 
 
-def _encode(i):
+def _cgroup_quota_cpus():
+    """CPUs' worth of time the cgroup grants (cpu.max of cgroup v2, cfs quota of v1), or None when unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0 and period > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def _threads_per_core(cpus):
+    """hardware threads per physical core among `cpus` (1 when the topology files are not readable)."""
+    try:
+        seen = set()
+        for c in cpus:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                seen.add(f.read().strip())
+        return max(1, round(len(cpus) / max(1, len(seen))))
+    except OSError:
+        return 1
+
+
+def usable_cpus():
+    """{"visible": os.cpu_count(), "affinity": CPUs in the scheduler mask, "cgroup_quota": CPUs' worth of quota or None,
+    "usable": what a worker pool should be sized to, "threads_per_core": SMT width among the usable ones}"""
+    visible = os.cpu_count() or 1
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = list(range(visible))
+    quota = _cgroup_quota_cpus()
+    usable = len(aff)
+    if quota is not None:
+        usable = max(1, min(usable, int(math.floor(quota + 1e-9)) or 1))
+    return {"visible": visible, "affinity": len(aff), "cgroup_quota": quota, "usable": usable,
+            "threads_per_core": _threads_per_core(aff)}
+
+
+def _worker(idx, n_workers, seconds, ready, go, results):
+    """One all-cores worker: encode clips idx, idx + n_workers, ... (wrapping) until `seconds` have passed since `go`."""
     from oracle import oracle as O
-    pcm = _CLIPS[i % _CLIPS.shape[0]]
-    return len(O.encode_all(pcm.reshape(-1), pcm.shape[1], _RATE, pcm.shape[0], O.REF_STYLE))
+    n_avail, samples, ch = _CLIPS.shape
+    one = np.ascontiguousarray(_CLIPS[idx % n_avail]).reshape(-1)
+    O.encode_all(one[: 5120 * ch * 2], ch, _RATE, 5120 * 2, O.REF_STYLE)  # library loaded, pages touched
+    ready.release()
+    go.wait()
+    t0 = time.perf_counter()
+    n, k = 0, idx
+    while True:
+        pcm = np.ascontiguousarray(_CLIPS[k % n_avail]).reshape(-1)
+        O.encode_all(pcm, ch, _RATE, samples, O.REF_STYLE)
+        n += 1
+        k += n_workers
+        if time.perf_counter() - t0 >= seconds:
+            break
+    results.put((idx, n, time.perf_counter() - t0))
+
+
+def all_cores_leg(workers, seconds):
+    """Throughput of `workers` processes that all start together and each encode whole clips for >= `seconds`:
+    clips done / the time until the LAST worker finished its last clip."""
+    ctx = mp.get_context("fork")
+    ready, go, results = ctx.Semaphore(0), ctx.Event(), ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(i, workers, seconds, ready, go, results)) for i in range(workers)]
+    for p in procs:
+        p.start()
+    for _ in procs:
+        ready.acquire()
+    go.set()
+    got = [results.get() for _ in procs]
+    for p in procs:
+        p.join()
+    clips = sum(n for _, n, _ in got)
+    wall = max(dt for _, _, dt in got)
+    return clips, wall, min(dt for _, _, dt in got)
 
 
 def main(argv):
@@ -44,26 +137,46 @@ def main(argv):
     O.lib()
     _CLIPS = np.load(path, mmap_mode="r")  # [n, samples, channels] int16
     n_avail, samples, ch = _CLIPS.shape
-    digests = []
+    digests, encoded = [], []
     t0 = time.perf_counter()
     for i in range(n_avail):
         enc = O.encode_all(np.ascontiguousarray(_CLIPS[i]).reshape(-1), ch, _RATE, samples, O.REF_STYLE)
         digests.append(hashlib.sha256(enc).hexdigest())
+        encoded.append(enc)
         if time.perf_counter() - t0 > budget:
             break
     dt = time.perf_counter() - t0
     n = len(digests)
     res = {"one_thread": {"value": n * samples * ch / dt, "clips": n, "seconds": dt, "samples": n * samples * ch},
-           "sha256": digests}
+           "sha256": digests, "cpus": usable_cpus()}
+    if "--no-decode" not in argv:
+        # decode_all on the streams just written (untimed: the sha256 of each clip's PCM, taken after the clock stops)
+        bufs = [np.frombuffer(e, dtype=np.uint8) for e in encoded]
+        pcm_out = np.empty(samples * ch, dtype=np.int16)
+        dec_digests, t_dec, n_dec = [], 0.0, 0
+        for b in bufs:
+            t1 = time.perf_counter()
+            O.decode_all_into(b, pcm_out)
+            t_dec += time.perf_counter() - t1
+            n_dec += 1
+            dec_digests.append(hashlib.sha256(pcm_out.tobytes()).hexdigest())
+            if t_dec > budget / 2:
+                break
+        res["decode_one_thread"] = {"value": n_dec * samples * ch / t_dec, "clips": n_dec, "seconds": t_dec,
+                                    "samples": n_dec * samples * ch}
+        res["decode_sha256"] = dec_digests
+    del encoded
     if all_cores:
-        cores = os.cpu_count() or 1
-        jobs = max(cores, min(4 * cores, 64))
-        with mp.get_context("fork").Pool(cores) as pool:
-            pool.map(_encode, range(cores))  # warm: page the clips in, load the library in every worker
-            t0 = time.perf_counter()
-            pool.map(_encode, range(jobs))
-            dta = time.perf_counter() - t0
-        res["all_cores"] = {"value": jobs * samples * ch / dta, "cores": cores, "clips": jobs, "seconds": dta}
+        cpus = res["cpus"]
+        workers = cpus["usable"]
+        per_clip_s = dt / n
+        seconds = max(2.0, min(budget / 3.0, 6.0), 3.0 * per_clip_s)  # >= 2 s and >= 3 clips per worker
+        clips, wall, first_done = all_cores_leg(workers, seconds)
+        value = clips * samples * ch / wall
+        res["all_cores"] = {"value": value, "cores": workers, "clips": clips, "seconds": wall,
+                            "first_worker_done_after_s": first_done,
+                            "scaling_efficiency": value / (res["one_thread"]["value"] * workers),
+                            "threads_per_core": cpus["threads_per_core"]}
     print(json.dumps(res))
 
 

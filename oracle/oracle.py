@@ -235,6 +235,21 @@ def decode_all(data):
     return ch.value, sr.value, out
 
 
+def decode_all_into(buf, out):
+    """decode_all (src/lib.rs:713-747) in ONE pass into a caller-allocated int16 array that is large enough (decode_all
+    above walks the stream twice: once for the count).  buf: uint8 ndarray, out: int16 ndarray.  Returns
+    (channels, sample_rate, samples written) -- the timed form of bench.py's CPU decode baseline."""
+    n = C.c_size_t(0)
+    ch, sr = C.c_uint8(0), C.c_uint32(0)
+    rc = lib().oq_decode_all(buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(ch), C.byref(sr),
+                             out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+    if rc:
+        raise OracleError(DEC_ERRORS[rc], rc)
+    if n.value > out.size:
+        raise ValueError(f"stream holds {n.value} samples, buffer {out.size}")
+    return ch.value, sr.value, n.value
+
+
 class OracleDecoder:
     """QoaDecoder<Cursor<Vec<u8>>> (src/lib.rs:117-201, 627-693) over the C oracle."""
 

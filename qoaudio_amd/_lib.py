@@ -17,7 +17,7 @@ SYMBOLS = [
     "qoa_encode_strerror", "qoa_decode_strerror", "qoa_last_error_detail", "qoa_version",
     "qoa_encoded_size", "qoa_frame_size",
     "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
-    "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_encode_all",
+    "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_debug_encoder_set_plan_flags", "qoa_encode_all",
     "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_launch_info", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
     "qoa_encode_batch_host", "qoa_host_pipeline_create", "qoa_host_pipeline_free", "qoa_host_pipeline_encode",
     "qoa_host_pipeline_decode", "qoa_decode_batch_host",
@@ -107,6 +107,7 @@ def lib():
     L.qoa_encoder_get_lms.argtypes = [vp, vp]
     L.qoa_encoder_set_lms.argtypes = [vp, vp]
     L.qoa_debug_encode_slice.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.qoa_debug_encoder_set_plan_flags.argtypes = [vp, C.c_uint32]
     L.qoa_encode_all.argtypes = [vp, sz, C.POINTER(Desc), vp, sz, szp]
     L.qoa_encode_plan_create.argtypes = [C.POINTER(Clip), sz, C.c_uint32, C.POINTER(vp)]
     L.qoa_encode_plan_free.argtypes = [vp]

@@ -180,6 +180,13 @@ class QoaEncoder:
             raise EncodeError(rc)
         return s
 
+    def debug_set_plan_flags(self, flags: int) -> None:
+        """Test hook (qoa_debug_encoder_set_plan_flags): later launches of this handle take a plan's step-form switches
+        (batch.PLAN_*); the bytes do not depend on them."""
+        rc = _lib.lib().qoa_debug_encoder_set_plan_flags(self._h, flags)
+        if rc:
+            raise EncodeError(rc)
+
     def set_lms_state(self, state) -> None:
         s = np.ascontiguousarray(state, dtype=np.int32).reshape(self._desc.channels, 8)
         rc = _lib.lib().qoa_encoder_set_lms(self._h, s.ctypes.data_as(C.c_void_p))

@@ -614,6 +614,7 @@ extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, cons
 // ------------------------------------------------------------------------------------------------
 struct qoa_encoder {
     qoa_desc desc{};
+    uint32_t debug_plan_flags = 0; // qoa_debug_encoder_set_plan_flags: QOA_PLAN_* step-form switches for the handle's launches
     hipStream_t stream = nullptr;
     DevBuf lms, chains, pcm, out;
     ~qoa_encoder() { if (stream) (void)hipStreamDestroy(stream); }
@@ -671,9 +672,10 @@ static int encoder_run(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint3
     HIP_TRY(hipMemcpyAsync(enc->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice, enc->stream),
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(enc->pcm.p, pcm, n_i16 * 2, hipMemcpyHostToDevice, enc->stream), QOA_ENCODE_IO_ERROR);
-    HIP_TRY(launch_encode(pick_cpw(v.size(), 0), enc->desc.channels, (const int16_t *)enc->pcm.p, (uint8_t *)enc->out.p,
-                          (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p, 0u, nullptr,
-                          enc->stream),
+    HIP_TRY(launch_encode(pick_cpw(v.size(), enc->debug_plan_flags), enc->desc.channels, (const int16_t *)enc->pcm.p,
+                          (uint8_t *)enc->out.p, (const EncChain *)enc->chains.p, (unsigned)v.size(), (int32_t *)enc->lms.p,
+                          plan_kernel_flags(enc->debug_plan_flags) | ((enc->debug_plan_flags & QOA_PLAN_LDS_TABLES) ? 16u : 0u),
+                          nullptr, enc->stream),
             QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpyAsync(out, enc->out.p, out_bytes, hipMemcpyDeviceToHost, enc->stream), QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipStreamSynchronize(enc->stream), QOA_ENCODE_IO_ERROR);
@@ -722,6 +724,14 @@ extern "C" int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state) {
     if (!enc || !state) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpy(enc->lms.p, state, enc->desc.channels * 8 * sizeof(int32_t), hipMemcpyHostToDevice),
             QOA_ENCODE_IO_ERROR);
+    return QOA_OK;
+}
+
+// Test hook: the handle's launches take the step-form switches of a plan (QOA_PLAN_* debug flags; QOA_PLAN_COUNTERS is
+// ignored) -- the fuzz tests drive every form from hostile LMS states through set_lms + encode_frame.
+extern "C" int qoa_debug_encoder_set_plan_flags(qoa_encoder *enc, uint32_t flags) {
+    if (!enc) return fail_msg("null encoder", QOA_ENCODE_IO_ERROR);
+    enc->debug_plan_flags = flags & ~(uint32_t)QOA_PLAN_COUNTERS;
     return QOA_OK;
 }
 

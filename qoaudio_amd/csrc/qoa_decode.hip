@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                                          : "=&s"(keep)
                                          : "v"(out_ptr[o] + (unsigned)(ln * LNB / 4096 * 4096)), "v"(vv[o][ln - l0]),
                                            "s"((1ull << (LPL * valid)) - 1ull), "n"(ln * LNB % 4096) // (13-bit signed immediate)
-                                         : "memory"); // (always nt: a handful of lanes)
+                                         : "memory", "scc"); // (always nt: a handful of lanes; s_and_b64 writes SCC)
                         }
                     }
                 });

@@ -18,6 +18,70 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- fuzz seed -------------------------------------------------------------------------------------------------------------
+# Every randomised GPU test draws from np.random.default_rng([FUZZ_SEED, case]).  FUZZ_SEED changes with every change of
+# the tree -- so the driver's round-end run, the only execution the builder does not control, explores inputs no earlier
+# run has seen -- and is printed in the header and with every failing test; QOA_FUZZ_SEED=<n> reproduces a run.  The
+# snapshot that travels to the GPU box has no .git, so the seed is the digest of the sources themselves (what a commit id
+# is a digest of): kernels, generators, host code, the oracle and the tests.
+_FUZZ_TREE = ("qoaudio_amd", "include", "oracle", "tests", "tools/gen_slice_asm.py", "tools/gen_decode_asm.py", "bench.py")
+_FUZZ_EXT = (".py", ".hip", ".cpp", ".h", ".hpp", ".inc", ".c")
+
+
+def _tree_digest():
+    import hashlib
+    h = hashlib.sha1()
+    files = []
+    for top in _FUZZ_TREE:
+        path = os.path.join(ROOT, top)
+        if os.path.isfile(path):
+            files.append(path)
+            continue
+        for d, dirs, names in os.walk(path):
+            dirs[:] = sorted(x for x in dirs if x not in ("__pycache__", "_ref", "golden", "bin"))
+            files += [os.path.join(d, n) for n in sorted(names) if n.endswith(_FUZZ_EXT)]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _fuzz_seed():
+    env = os.environ.get("QOA_FUZZ_SEED")
+    if env:
+        return int(env, 0), "QOA_FUZZ_SEED"
+    return int(_tree_digest()[:8], 16), "digest of the source tree"
+
+
+FUZZ_SEED, FUZZ_SEED_FROM = _fuzz_seed()
+
+
+def fuzz_rng(case):
+    """The generator of fuzz case `case` (an int or a tuple of ints) under this run's seed."""
+    key = [FUZZ_SEED] + (list(case) if isinstance(case, (tuple, list)) else [int(case)])
+    return np.random.default_rng(key)
+
+
+def pytest_report_header(config):
+    return f"qoa fuzz seed: {FUZZ_SEED} ({FUZZ_SEED_FROM}); reproduce with QOA_FUZZ_SEED={FUZZ_SEED}"
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    # (-q drops the header: the seed must still be in the log of the driver's `pytest -x -q -m gpu`)
+    terminalreporter.write_line(f"qoa fuzz seed: {FUZZ_SEED} ({FUZZ_SEED_FROM}), QOA_FUZZ_SCALE="
+                                f"{os.environ.get('QOA_FUZZ_SCALE', '(default)')}")
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == "call" and rep.failed and "fuzz" in item.nodeid:
+        rep.sections.append(("qoa fuzz seed", f"QOA_FUZZ_SEED={FUZZ_SEED} QOA_FUZZ_SCALE={os.environ.get('QOA_FUZZ_SCALE', '(default)')} "
+                                              f"reproduces this run ({item.nodeid})"))
+
+
 def pytest_sessionstart(session):
     """A fresh checkout has no libqoaudio_amd.so (it is git-ignored): build it once for the suite.  hipcc
     cross-compiles for gfx950 without a GPU.  (The product itself never builds or falls back: qoaudio_amd._lib

@@ -47,8 +47,9 @@ def test_two_rank_control_flow_on_one_gpu(gpu, oracle):
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    assert len(lines) == 2 and lines[0].startswith('{"bench_extras"')  # the lab records, then the contract's line (last, <= 6 KB)
+    assert len(lines[-1]) <= 6144
+    line = json.loads(lines[-1])
     assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
     assert line["bit_exact_vs_oracle"] is True and line["gathered_shards_bit_exact_vs_oracle"] is True
     assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)

@@ -189,3 +189,39 @@ def test_k2u_flush_stores_issue_at_raised_priority(kernels):
             assert raised_stores > 0 and plain_stores == 0, (name, raised_stores, plain_stores)
             seen += 1
     assert seen >= 3
+
+
+def test_k2u_masked_store_restores_exec(kernels):
+    """3 / 5 / 6 / 7 channels: the last store-role group of a frame count that is no multiple of 8 runs under a lane mask inside
+    one asm statement (`s_mov_b64 save, exec; s_and_b64 exec, exec, mask; global_store_dwordx4; s_mov_b64 exec, save`).  The
+    statement declares SCC clobbered (advisor, round 4: `s_and_b64` writes it); what can be checked on the binary is that
+    every narrowing of EXEC is undone from the SAME saved pair right behind the one store it covers, and that no SCC reader
+    (`s_cselect`, `s_cbranch_scc*`, `s_addc`, `s_subb`) sits between the narrowing and the next SCC writer -- i.e. nobody
+    consumes the SCC the statement left behind."""
+    seen = 0
+    scc_readers = ("s_cselect", "s_cbranch_scc", "s_addc_u32", "s_subb_u32", "s_cmov")
+    for name, ins in kernels.items():
+        m = re.search(r"qoa_decode_uniform_kernelILi(\d+)ELi(\d+)E", name)
+        if not m or int(m.group(1)) not in (3, 5, 6, 7):
+            continue
+        n_masked = 0
+        for k, i in enumerate(ins):
+            if not re.match(r"s_and_b64 exec, exec, s\[\d+:\d+\]", i) or k + 1 >= len(ins):
+                continue
+            if ins[k + 1].split()[0] != "global_store_dwordx4":
+                continue  # (hipcc's own control flow narrows EXEC too: `s_and_b64 exec, exec, ..` + `s_cbranch_execz`)
+            save = re.match(r"s_mov_b64 (s\[\d+:\d+\]), exec", ins[k - 1])
+            assert save, (name, ins[k - 2:k + 3])
+            assert ins[k + 1].split()[0] == "global_store_dwordx4", (name, ins[k:k + 3])
+            assert ins[k + 2] == f"s_mov_b64 exec, {save.group(1)}", (name, ins[k - 1:k + 3])
+            for j in ins[k + 3:]:
+                op = j.split()[0]
+                assert not op.startswith(scc_readers), (name, k, j)
+                if op.startswith(("s_cmp", "s_and_b", "s_or_b", "s_add_", "s_sub_", "s_lshl", "s_lshr", "s_bitcmp", "s_andn2", "s_xor_b")):
+                    break  # SCC rewritten before anybody read it
+                if op.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                    break  # (a branch that is not on SCC: the next block starts with its own compares)
+            n_masked += 1
+        assert n_masked > 0, name
+        seen += 1
+    assert seen >= 4
