@@ -440,6 +440,42 @@ def final_line(full: dict) -> dict:
     return out
 
 
+def preflight(qdist, rank, world, local_rank, dev):
+    """Before the timed loop of an N > 1 run: what the first run on a multi-GPU box should establish before anything is
+    measured -- how many devices every rank sees, the peer-access matrix (row = this rank's
+    device, as hipDeviceCanAccessPeer reports it), and a 1 MB gather to rank 0 through the very function the timed loop
+    uses (RCCL when the backend is nccl), checked byte for byte and timed (second call: the first builds the communicator's
+    channels).  Failures are reported in the record, they do not end the run."""
+    rec = {"backend": dist.get_backend(), "world_size": world}
+    try:
+        ndev = torch.cuda.device_count()
+        row = "".join("1" if (j == local_rank or torch.cuda.can_device_access_peer(local_rank, j)) else "0" for j in range(ndev))
+        rows = [None] * world
+        dist.all_gather_object(rows, (rank, local_rank, ndev, torch.cuda.get_device_name(local_rank), row))
+        rec["device_count_per_rank"] = [r[2] for r in rows]
+        rec["devices"] = sorted({r[3] for r in rows})
+        rec["peer_access_rows"] = {f"rank{r[0]}:dev{r[1]}": r[4] for r in rows}
+        rec["all_peers_accessible"] = all("0" not in r[4] for r in rows)
+        x = torch.full((1, 1 << 20), rank + 1, dtype=torch.uint8, device=dev)
+        out = torch.zeros((world, 1 << 20), dtype=torch.uint8, device=dev) if rank == 0 else None
+        ms = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            work, _ = qdist.gather_encoded_async(x, world, dst=0, out=out)
+            work.wait()
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        rec["gather_1mb_ms"] = [round(v, 3) for v in ms]
+        if rank == 0:
+            want = torch.arange(1, world + 1, dtype=torch.uint8, device=dev).view(world, 1).expand(world, 1 << 20)
+            rec["gather_1mb_ok"] = bool(torch.equal(out, want))
+    except Exception as e:
+        rec["error"] = f"{type(e).__name__}: {e}"[:300]
+    return rec
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -558,6 +594,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the K1 records outside the headline shape")
+    ap.add_argument("--preflight", action="store_true", help="N > 1: device count, peer-access matrix and a 1 MB gather "
+                                                             "before the timed loop (the default for N > 1; see --no-preflight)")
+    ap.add_argument("--no-preflight", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (pinned host memory) record")
     ap.add_argument("--extras-file", default="", help="also write the full record (the bench_extras line) to this file")
     ap.add_argument("--abi-multi", action="store_true",
@@ -584,6 +623,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    pre = preflight(qdist, rank, world, local_rank, dev) if world > 1 and not args.no_preflight else None
 
     n_clips, ch = args.clips, args.channels
     samples = args.frames * 5120
@@ -668,6 +709,8 @@ def main():
     }
     if enc_traffic_note:
         result["roofline"]["traffic_note"] = enc_traffic_note
+    if pre is not None:
+        result["preflight"] = pre
     if world > 1:
         result["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
         result["dist_backend"] = dist.get_backend()

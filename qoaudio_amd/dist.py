@@ -50,16 +50,50 @@ class _DoneWork:
         return True
 
 
+class _PaddedWork:
+    """An asynchronous gather of an UNEVEN partition: every rank sent n_max rows (its shard padded with zero rows), rank dst
+    received them into scratch blocks; wait() waits for the collective and then trims the blocks into `out` (on the
+    current stream for device tensors: the work's wait() orders that stream behind the collective)."""
+
+    def __init__(self, work, parts, counts, out):
+        self._work, self._parts, self._counts, self._out = work, parts, counts, out
+
+    def wait(self):
+        ok = self._work.wait()
+        if self._parts is not None:
+            for (a, b), p in zip(self._counts, self._parts):
+                self._out[a:b].copy_(p[: b - a])
+            self._parts = None
+        return ok
+
+
 def gather_encoded_async(local: torch.Tensor, n_total: int, dst: int = 0, group=None,
                          out: Optional[torch.Tensor] = None):
-    """Even-partition gather that returns (work, out): the collective is enqueued (async_op=True) and the caller
-    waits on `work` before it reuses `local` or reads `out`.  Lets step i's gather run on the communication
-    stream while step i+1 encodes into a second output buffer (bench.py, N > 1)."""
+    """Gather that returns (work, out): the collective is enqueued (async_op=True) and the caller waits on `work`
+    before it reuses `local` or reads `out`.  Lets step i's gather run on the communication stream while step i+1
+    encodes into a second output buffer (bench.py, N > 1).  With an even partition every peer's shard lands straight in
+    its row block of `out`; an uneven one (n_total % world != 0) takes the padded path: equal-sized sends, scratch
+    blocks on dst, trimmed into `out` by work.wait()."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = [shard_range(n_total, r, world) for r in range(world)]
-    assert all(b - a == local.shape[0] for a, b in counts), "gather_encoded_async needs an even partition"
+    assert local.shape[0] == counts[rank][1] - counts[rank][0], "shard does not match shard_range()"
+    n_max = max(b - a for a, b in counts)
+    even = all(b - a == n_max for a, b in counts)
     send = local if local.is_contiguous() else local.contiguous()
+    if not even:
+        if send.shape[0] != n_max:  # (a fresh buffer per call: the caller may overwrite `local` only after wait())
+            padded = torch.zeros((n_max, local.shape[1]), dtype=local.dtype, device=local.device)
+            padded[: local.shape[0]] = send
+            send = padded
+        if send.is_cuda and dist.get_backend(group) == "gloo":
+            send = send.cpu()
+        if rank != dst:
+            return _PaddedWork(dist.gather(send, gather_list=None, dst=dst, group=group, async_op=True), None, counts, None), None
+        if out is None:
+            out = torch.empty((n_total, local.shape[1]), dtype=local.dtype, device=local.device)
+        parts = [torch.empty((n_max, local.shape[1]), dtype=send.dtype, device=send.device) for _ in range(world)]
+        return _PaddedWork(dist.gather(send, gather_list=parts, dst=dst, group=group, async_op=True), parts, counts, out), out
     if send.is_cuda and dist.get_backend(group) == "gloo":  # debug path only (see init_from_env): host-staged, synchronous
         host = send.cpu()
         parts = [torch.empty_like(host) for _ in counts] if rank == dst else None

@@ -51,6 +51,8 @@ def test_two_rank_control_flow_on_one_gpu(gpu, oracle):
     assert len(lines[-1]) <= 6144
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
+    pre = line["preflight"]  # (N > 1 default: device count, peer-access rows, a checked 1 MB gather before the timed loop)
+    assert "error" not in pre and pre["gather_1mb_ok"] is True and len(pre["peer_access_rows"]) == 2 and pre["world_size"] == 2
     assert line["bit_exact_vs_oracle"] is True and line["gathered_shards_bit_exact_vs_oracle"] is True
     assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)
     assert line["config"]["samples_per_step"] == 2 * 64 * 8 * 5120 * 2
