@@ -318,7 +318,20 @@ def signal_classes(q, batch, synth, dev, stream, ch, rate, n_clips=256, frames=6
                                   "wavefront_slices_on_32bit_step": c[5], "penalty_form_declines": c[7],
                                   "wide_form_declines": c[8], "wavefront_slices_on_wide_form": c[9],
                                   "slices_total": n_clips * ch * frames * 256}}
-        del plan, cplan, pcm
+        # what the class cost wavefront by wavefront (the recording instantiation of K1: one record per wavefront at its exit,
+        # no atomics): measured cycles per slice over the wavefronts, the slowest one's form mix, and the bound it is held
+        # against -- every slice on the 32-bit block statement, 842 issue slots x 4.06 cycles x 1.10 of loop overhead (include/qoaudio_amd.h)
+        wplan = batch.EncodePlan(clips, batch.PLAN_WAVE_STATS)
+        wplan.run(pcm, out, stream)
+        ws = wplan.wave_stats()
+        res[kind]["per_wavefront"] = {
+            "cycles_per_slice_p50": round(ws["cycles_per_slice"]["p50"], 1), "cycles_per_slice_max": round(ws["cycles_per_slice"]["max"], 1),
+            "bound_cycles_per_slice": round(ws["bound_cycles_per_slice"], 1),
+            "max_over_bound": round(ws["cycles_per_slice"]["max"] / ws["bound_cycles_per_slice"], 3),
+            "slowest_wavefront_form_mix": {k: v for k, v in ws["slowest_wavefront"]["form_mix"].items() if v},
+            "slowest_predicted_cycles_per_slice": round(ws["slowest_wavefront"]["predicted_cycles_per_slice"], 1),
+            "wavefront_slices_per_form": {k: v for k, v in ws["slices"].items() if v}}
+        del plan, cplan, wplan, pcm
     if "music" in res:
         for kind in ("white", "silence", "fixture", "loud"):
             if kind in res:

@@ -4,6 +4,9 @@
 //! `rafaelcaricio/qoaudio` 1.0 (`src/lib.rs` of the reference; line numbers below refer to it), forwarded to
 //! the C ABI in `include/qoaudio_amd.h`.  The reference forbids unsafe code; an FFI shim cannot.
 //!
+//! Round 5: the `extern "C"` block binds EVERY non-debug symbol of the header (tests/test_rust_shim_abi.py fails when one is
+//! missing) and the batch entry points have safe wrappers (`EncodePlan`, `DecodePlan`, `HostPipeline`, `stream_scan`).
+//!
 //! Every public signature equals the reference's (`mode()` and `current_frame_header()` return references to values
 //! cached in the handle, as `src/lib.rs:180-188` do).  tests/test_rust_shim_abi.py checks the `extern "C"` block below
 //! against `include/qoaudio_amd.h` symbol by symbol (argument count, pointer depth, constness, integer width) -- the
@@ -69,14 +72,59 @@ mod ffi {
         pub out_offset: u64,
         pub desc: qoa_desc,
     }
+    #[repr(C)]
+    #[derive(Default, Clone, Copy)]
+    pub struct qoa_launch_shape {
+        pub struct_bytes: u32,
+        pub wavefronts: u32,
+        pub chains_per_wavefront: u32,
+        pub lds_table_form: u32,
+        pub helper_wavefronts: u32,
+        pub launches: u32,
+    }
+    #[repr(C)]
+    #[derive(Default, Clone, Copy)]
+    pub struct qoa_wave_stats {
+        pub struct_bytes: u32,
+        pub wavefronts: u32,
+        pub slices: [u64; 8],
+        pub issue_slots: [u32; 8],
+        pub cycles_per_issue: f64,
+        pub loop_overhead: f64,
+        pub bound_cycles_per_slice: f64,
+        pub cycles_per_slice_min: f64,
+        pub cycles_per_slice_p50: f64,
+        pub cycles_per_slice_max: f64,
+        pub slowest_wavefront: u32,
+        pub slowest_channels: u32,
+        pub slowest_slices_of_chain: u32,
+        pub slowest_slices: [u32; 8],
+        pub slowest_predicted_cycles_per_slice: f64,
+    }
+    #[repr(C)]
+    #[derive(Default)]
+    pub struct qoa_stream_info {
+        pub mode: qoa_mode,
+        pub terminal: c_int,
+        pub in_new: c_int,
+        pub n_frames: u64,
+        pub n_samples: u64,
+    }
     pub enum qoa_encoder {}
     pub enum qoa_decoder {}
     pub enum qoa_multi {}
+    pub enum qoa_encode_plan {}
+    pub enum qoa_decode_plan {}
+    pub enum qoa_host_pipeline {}
     /// `int64_t (*)(void *ctx, uint8_t *buf, size_t len)`: bytes stored, 0 at the end of the stream, negative on error
     pub type qoa_read_fn = unsafe extern "C" fn(*mut c_void, *mut u8, usize) -> i64;
     extern "C" {
+        pub fn qoa_encode_strerror(code: c_int) -> *const c_char;
+        pub fn qoa_decode_strerror(code: c_int) -> *const c_char;
         pub fn qoa_last_error_detail() -> *const c_char;
+        pub fn qoa_version() -> *const c_char;
         pub fn qoa_encoded_size(channels: u32, samples: u32) -> usize;
+        pub fn qoa_frame_size(channels: u32, slices: u32) -> u16;
         pub fn qoa_encoder_new(desc: *const qoa_desc, out: *mut *mut qoa_encoder) -> c_int;
         pub fn qoa_encoder_free(enc: *mut qoa_encoder);
         pub fn qoa_encoder_encode(enc: *mut qoa_encoder, pcm: *const i16, n_i16: usize, out: *mut u8, cap: usize,
@@ -84,6 +132,44 @@ mod ffi {
         pub fn qoa_encoder_write_header(enc: *const qoa_encoder, out: *mut u8) -> c_int;
         pub fn qoa_encoder_encode_frame(enc: *mut qoa_encoder, pcm: *const i16, n_i16: usize, out: *mut u8,
                                         cap: usize, written: *mut usize, frame_len: *mut usize) -> c_int;
+        pub fn qoa_encoder_get_lms(enc: *mut qoa_encoder, state: *mut i32) -> c_int;
+        pub fn qoa_encoder_set_lms(enc: *mut qoa_encoder, state: *const i32) -> c_int;
+        pub fn qoa_encode_all(pcm: *const i16, n_i16: usize, desc: *const qoa_desc, out: *mut u8, cap: usize,
+                              written: *mut usize) -> c_int;
+        // batches on device-resident buffers: the entry points through which a host reaches the kernels' full rate
+        pub fn qoa_encode_plan_create(clips: *const qoa_clip, n_clips: usize, flags: u32, out: *mut *mut qoa_encode_plan) -> c_int;
+        pub fn qoa_encode_plan_free(plan: *mut qoa_encode_plan);
+        pub fn qoa_encode_plan_bytes(plan: *const qoa_encode_plan, pcm_bytes: *mut u64, out_bytes: *mut u64,
+                                     samples_i16: *mut u64) -> c_int;
+        pub fn qoa_encode_plan_launch_info(plan: *const qoa_encode_plan, wavefronts: *mut u32, chains_per_wavefront: *mut u32,
+                                           lds_table_form: *mut u32) -> c_int;
+        pub fn qoa_encode_plan_launch_shape(plan: *const qoa_encode_plan, shape: *mut qoa_launch_shape) -> c_int;
+        pub fn qoa_encode_plan_run(plan: *mut qoa_encode_plan, d_pcm: *const i16, d_out: *mut u8, stream: *mut c_void) -> c_int;
+        pub fn qoa_encode_plan_stats(plan: *mut qoa_encode_plan, declined_slices: *mut u64, unpacked_slices: *mut u64,
+                                     speculation_misses: *mut u64) -> c_int;
+        pub fn qoa_encode_plan_counters(plan: *mut qoa_encode_plan, out: *mut u64, n: usize) -> c_int;
+        pub fn qoa_encode_plan_wave_stats(plan: *mut qoa_encode_plan, out: *mut qoa_wave_stats) -> c_int;
+        pub fn qoa_decode_plan_from_streams(streams: *const *const u8, len: *const usize, in_offset: *const u64,
+                                            out_offset: *const u64, n_streams: usize, status: *mut c_int,
+                                            samples_out: *mut u64, out: *mut *mut qoa_decode_plan) -> c_int;
+        pub fn qoa_decode_plan_from_clips(clips: *const qoa_clip, n_clips: usize, out: *mut *mut qoa_decode_plan) -> c_int;
+        pub fn qoa_decode_plan_free(plan: *mut qoa_decode_plan);
+        pub fn qoa_decode_plan_bytes(plan: *const qoa_decode_plan, in_bytes: *mut u64, pcm_bytes: *mut u64,
+                                     samples_i16: *mut u64) -> c_int;
+        pub fn qoa_decode_plan_run(plan: *mut qoa_decode_plan, d_in: *const u8, d_out: *mut i16, stream: *mut c_void) -> c_int;
+        pub fn qoa_decode_plan_mismatches(plan: *mut qoa_decode_plan, count: *mut u32) -> c_int;
+        // batches on host-resident buffers: the time-sliced pipeline
+        pub fn qoa_encode_batch_host(clips: *const qoa_clip, n_clips: usize, h_pcm: *const i16, h_out: *mut u8,
+                                     chunk_frames: u32) -> c_int;
+        pub fn qoa_decode_batch_host(clips: *const qoa_clip, n_clips: usize, h_enc: *const u8, h_pcm: *mut i16,
+                                     chunk_frames: u32) -> c_int;
+        pub fn qoa_host_pipeline_create(out: *mut *mut qoa_host_pipeline) -> c_int;
+        pub fn qoa_host_pipeline_free(p: *mut qoa_host_pipeline);
+        pub fn qoa_host_pipeline_encode(p: *mut qoa_host_pipeline, clips: *const qoa_clip, n_clips: usize, h_pcm: *const i16,
+                                        h_out: *mut u8, chunk_frames: u32) -> c_int;
+        pub fn qoa_host_pipeline_decode(p: *mut qoa_host_pipeline, clips: *const qoa_clip, n_clips: usize, h_enc: *const u8,
+                                        h_pcm: *mut i16, chunk_frames: u32) -> c_int;
+        pub fn qoa_stream_scan(bytes: *const u8, len: usize, info: *mut qoa_stream_info) -> c_int;
         pub fn qoa_decoder_new(bytes: *const u8, len: usize, out: *mut *mut qoa_decoder) -> c_int;
         pub fn qoa_decoder_new_reader(read: qoa_read_fn, ctx: *mut c_void, out: *mut *mut qoa_decoder) -> c_int;
         pub fn qoa_decoder_new_streaming(out: *mut *mut qoa_decoder) -> c_int;
@@ -92,12 +178,14 @@ mod ffi {
         pub fn qoa_decoder_current_frame_header(dec: *const qoa_decoder, h: *mut qoa_frame_header) -> c_int;
         pub fn qoa_decoder_total_duration(dec: *const qoa_decoder) -> c_double;
         pub fn qoa_decoder_next(dec: *mut qoa_decoder, item: *mut qoa_item) -> c_int;
+        pub fn qoa_decoder_read_samples(dec: *mut qoa_decoder, out: *mut i16, cap: usize) -> usize;
         pub fn qoa_decoder_decode_frame(dec: *mut qoa_decoder, frame: *const u8, len: usize, out: *mut i16,
                                         cap: usize, n_out: *mut usize) -> c_int;
         pub fn qoa_decode_all(bytes: *const u8, len: usize, channels: *mut u8, sample_rate: *mut u32,
                               out: *mut i16, cap: usize, n_out: *mut usize) -> c_int;
         // multi-GPU batches in one process (no counterpart in the reference; include/qoaudio_amd.h)
         pub fn qoa_multi_create(devices: *const c_int, n_devices: c_int, out: *mut *mut qoa_multi) -> c_int;
+        pub fn qoa_multi_create_flags(devices: *const c_int, n_devices: c_int, flags: u32, out: *mut *mut qoa_multi) -> c_int;
         pub fn qoa_multi_free(m: *mut qoa_multi);
         pub fn qoa_multi_shard(n_clips: usize, n_devices: c_int, index: c_int, first: *mut usize, count: *mut usize) -> c_int;
         pub fn qoa_multi_encode(m: *mut qoa_multi, clips: *const qoa_clip, n_clips: usize, pcm: *const *const i16,
@@ -510,4 +598,309 @@ impl MultiGpu {
 }
 impl Drop for MultiGpu {
     fn drop(&mut self) { unsafe { ffi::qoa_multi_free(self.h) } }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Batches.  No counterpart in the reference (per clip this is `encode_all`, :760-763, and `decode_all`, :713-747): the
+// entry points through which a Rust host reaches the kernels' rate -- `EncodePlan` / `DecodePlan` on buffers that already
+// sit in device memory (42 G samples/s encode, 2 T samples/s decode on one MI355X), `HostPipeline` from / to host memory
+// (PCIe-bound, ~27 G samples/s).  Flags: the `QOA_PLAN_*` constants of include/qoaudio_amd.h.
+// ------------------------------------------------------------------------------------------------------------------------
+pub const QOA_PLAN_DEFAULT: u32 = 0;
+pub const QOA_PLAN_COUNTERS: u32 = 512;
+pub const QOA_PLAN_WAVE_STATS: u32 = 32768;
+
+fn ffi_clips(clips: &[BatchClip]) -> Vec<ffi::qoa_clip> {
+    clips.iter().map(|c| ffi::qoa_clip {
+        pcm_offset: c.pcm_offset, out_offset: c.out_offset,
+        desc: ffi::qoa_desc { channels: c.desc.channels, sample_rate: c.desc.sample_rate, samples: c.desc.samples } }).collect()
+}
+
+/// do all clips lie inside a PCM buffer of `n_i16` samples and an encoded buffer of `n_bytes` bytes?
+fn clips_fit(clips: &[BatchClip], n_i16: usize, n_bytes: usize) -> bool {
+    clips.iter().all(|c| {
+        let pcm_end = c.pcm_offset as u128 + c.desc.samples as u128 * c.desc.channels as u128;
+        let enc_end = c.out_offset as u128 + encoded_size(c.desc.channels, c.desc.samples) as u128;
+        pcm_end <= n_i16 as u128 && enc_end <= n_bytes as u128
+    })
+}
+
+/// `qoa_encoded_size` (:374-378)
+pub fn encoded_size(channels: u8, samples: u32) -> usize { unsafe { ffi::qoa_encoded_size(channels as u32, samples) } }
+/// `qoa_frame_size` (:602-604)
+pub fn frame_size(channels: u32, slices: u32) -> u16 { unsafe { ffi::qoa_frame_size(channels, slices) } }
+/// "qoaudio_amd <version> gfx950"
+pub fn version() -> String { unsafe { CStr::from_ptr(ffi::qoa_version()) }.to_string_lossy().into_owned() }
+/// The library's own Display strings of the two error enums (the `Display` impls above carry the same text).
+pub fn encode_strerror(code: i32) -> String { unsafe { CStr::from_ptr(ffi::qoa_encode_strerror(code)) }.to_string_lossy().into_owned() }
+pub fn decode_strerror(code: i32) -> String { unsafe { CStr::from_ptr(ffi::qoa_decode_strerror(code)) }.to_string_lossy().into_owned() }
+
+/// `encode_all` through the library's one-call entry point (`qoa_encode_all`): same result as `encode_all` above.
+pub fn encode_all_oneshot(sample_data: &[i16], desc: &QoaDesc) -> Result<Vec<u8>, EncodeError> {
+    let d = ffi::qoa_desc { channels: desc.channels, sample_rate: desc.sample_rate, samples: desc.samples };
+    let mut buf = vec![0u8; if (1..=8).contains(&desc.channels) { encoded_size(desc.channels, desc.samples) } else { 16 }];
+    let mut written = 0usize;
+    match unsafe { ffi::qoa_encode_all(sample_data.as_ptr(), sample_data.len(), &d, buf.as_mut_ptr(), buf.len(), &mut written) } {
+        0 => { buf.truncate(written); Ok(buf) }
+        c => Err(enc_err(c)),
+    }
+}
+
+impl QoaEncoder {
+    /// Carried LMS state, `[history[4], weights[4]]` per channel as full i32 (:70-74, :89): checkpoint / resume.
+    pub fn lms_state(&mut self) -> Result<Vec<[i32; 8]>, EncodeError> {
+        let mut flat = vec![0i32; self.channels as usize * 8];
+        match unsafe { ffi::qoa_encoder_get_lms(self.h, flat.as_mut_ptr()) } {
+            0 => Ok(flat.chunks_exact(8).map(|c| [c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]]).collect()),
+            c => Err(enc_err(c)),
+        }
+    }
+    pub fn set_lms_state(&mut self, state: &[[i32; 8]]) -> Result<(), EncodeError> {
+        if state.len() != self.channels as usize { return Err(EncodeError::InvalidChannels); }
+        let flat: Vec<i32> = state.iter().flatten().copied().collect();
+        match unsafe { ffi::qoa_encoder_set_lms(self.h, flat.as_ptr()) } { 0 => Ok(()), c => Err(enc_err(c)) }
+    }
+}
+
+impl<R: io::Read> QoaDecoder<R> {
+    /// Bulk form of `next()`: consecutive `Sample` items copied into `out`; stops early at the next frame header, the end or
+    /// an error (which the following `next()` returns).  Returns the count.
+    pub fn read_samples(&mut self, out: &mut [i16]) -> usize {
+        unsafe { ffi::qoa_decoder_read_samples(self.h, out.as_mut_ptr(), out.len()) }
+    }
+}
+
+/// `qoa_launch_shape`: how a plan's launches are shaped.
+#[derive(Debug, Clone, Copy, Default)]
+pub struct LaunchShape {
+    pub wavefronts: u32,
+    pub chains_per_wavefront: u32,
+    pub lds_table_form: bool,
+    pub helper_wavefronts: bool,
+    pub launches: u32,
+}
+
+/// `qoa_wave_stats`: what the last run of an `EncodePlan` created with `QOA_PLAN_WAVE_STATS` cost, wavefront by wavefront
+/// (include/qoaudio_amd.h explains the forms and the bound: clipped material runs at most ~1.6x slower than music).
+#[derive(Debug, Clone, Copy, Default)]
+pub struct WaveStats {
+    pub wavefronts: u32,
+    pub slices: [u64; 8],
+    pub issue_slots: [u32; 8],
+    pub cycles_per_issue: f64,
+    pub loop_overhead: f64,
+    pub bound_cycles_per_slice: f64,
+    pub cycles_per_slice_min: f64,
+    pub cycles_per_slice_p50: f64,
+    pub cycles_per_slice_max: f64,
+    pub slowest_wavefront: u32,
+    pub slowest_channels: u32,
+    pub slowest_slices_of_chain: u32,
+    pub slowest_wavefront_form_mix: [u32; 8],
+    pub slowest_predicted_cycles_per_slice: f64,
+}
+
+/// Chain table of a batch of clips, resident on the calling thread's current HIP device (`qoa_encode_plan_*`).
+pub struct EncodePlan {
+    h: *mut ffi::qoa_encode_plan,
+}
+unsafe impl Send for EncodePlan {}
+
+impl EncodePlan {
+    pub fn new(clips: &[BatchClip], flags: u32) -> Result<Self, EncodeError> {
+        let c = ffi_clips(clips);
+        let mut h = std::ptr::null_mut();
+        match unsafe { ffi::qoa_encode_plan_create(c.as_ptr(), c.len(), flags, &mut h) } {
+            0 => Ok(Self { h }),
+            e => Err(enc_err(e)),
+        }
+    }
+    /// `(pcm bytes read, encoded bytes written, i16 samples)` of one run
+    pub fn bytes(&self) -> (u64, u64, u64) {
+        let (mut a, mut b, mut c) = (0u64, 0u64, 0u64);
+        unsafe { ffi::qoa_encode_plan_bytes(self.h, &mut a, &mut b, &mut c) };
+        (a, b, c)
+    }
+    pub fn launch_shape(&self) -> LaunchShape {
+        let mut s = ffi::qoa_launch_shape { struct_bytes: std::mem::size_of::<ffi::qoa_launch_shape>() as u32, ..Default::default() };
+        unsafe { ffi::qoa_encode_plan_launch_shape(self.h, &mut s) };
+        LaunchShape { wavefronts: s.wavefronts, chains_per_wavefront: s.chains_per_wavefront, lds_table_form: s.lds_table_form != 0,
+                      helper_wavefronts: s.helper_wavefronts != 0, launches: s.launches }
+    }
+    /// `(wavefronts, chains per wavefront, LDS-table form)`: the older three-value form of `launch_shape`
+    pub fn launch_info(&self) -> (u32, u32, bool) {
+        let (mut a, mut b, mut c) = (0u32, 0u32, 0u32);
+        unsafe { ffi::qoa_encode_plan_launch_info(self.h, &mut a, &mut b, &mut c) };
+        (a, b, c != 0)
+    }
+    /// Enqueue the batch encode on `stream` (a `hipStream_t`, may be null).  Asynchronous.
+    /// # Safety
+    /// `d_pcm` / `d_out` must be device memory valid for every clip of the plan until the stream has run the launch.
+    pub unsafe fn run(&mut self, d_pcm: *const i16, d_out: *mut u8, stream: *mut c_void) -> Result<(), EncodeError> {
+        match ffi::qoa_encode_plan_run(self.h, d_pcm, d_out, stream) { 0 => Ok(()), e => Err(enc_err(e)) }
+    }
+    /// `(declined, unpacked, speculation misses)`; plans created with `QOA_PLAN_COUNTERS` only
+    pub fn stats(&mut self) -> Result<(u64, u64, u64), EncodeError> {
+        let (mut a, mut b, mut c) = (0u64, 0u64, 0u64);
+        match unsafe { ffi::qoa_encode_plan_stats(self.h, &mut a, &mut b, &mut c) } { 0 => Ok((a, b, c)), e => Err(enc_err(e)) }
+    }
+    pub fn counters(&mut self) -> Result<[u64; 10], EncodeError> {
+        let mut out = [0u64; 10];
+        match unsafe { ffi::qoa_encode_plan_counters(self.h, out.as_mut_ptr(), out.len()) } { 0 => Ok(out), e => Err(enc_err(e)) }
+    }
+    /// plans created with `QOA_PLAN_WAVE_STATS` only
+    pub fn wave_stats(&mut self) -> Result<WaveStats, EncodeError> {
+        let mut w = ffi::qoa_wave_stats { struct_bytes: std::mem::size_of::<ffi::qoa_wave_stats>() as u32, ..Default::default() };
+        match unsafe { ffi::qoa_encode_plan_wave_stats(self.h, &mut w) } {
+            0 => Ok(WaveStats { wavefronts: w.wavefronts, slices: w.slices, issue_slots: w.issue_slots, cycles_per_issue: w.cycles_per_issue,
+                                loop_overhead: w.loop_overhead, bound_cycles_per_slice: w.bound_cycles_per_slice,
+                                cycles_per_slice_min: w.cycles_per_slice_min, cycles_per_slice_p50: w.cycles_per_slice_p50,
+                                cycles_per_slice_max: w.cycles_per_slice_max, slowest_wavefront: w.slowest_wavefront,
+                                slowest_channels: w.slowest_channels, slowest_slices_of_chain: w.slowest_slices_of_chain,
+                                slowest_wavefront_form_mix: w.slowest_slices,
+                                slowest_predicted_cycles_per_slice: w.slowest_predicted_cycles_per_slice }),
+            e => Err(enc_err(e)),
+        }
+    }
+}
+impl Drop for EncodePlan {
+    fn drop(&mut self) { unsafe { ffi::qoa_encode_plan_free(self.h) } }
+}
+
+/// Frame table of a batch of encoded streams, resident on the current device (`qoa_decode_plan_*`).
+pub struct DecodePlan {
+    h: *mut ffi::qoa_decode_plan,
+    /// `from_streams`: per stream, `Ok(samples it yields)` or the error that ends it (after that many samples)
+    pub streams: Vec<(u64, Option<DecodeError>)>,
+}
+unsafe impl Send for DecodePlan {}
+
+impl DecodePlan {
+    /// Streams laid out as `EncodePlan::run` wrote them (`pcm_offset` = PCM destination, `out_offset` = encoded source).
+    pub fn from_clips(clips: &[BatchClip]) -> Result<Self, DecodeError> {
+        let c = ffi_clips(clips);
+        let mut h = std::ptr::null_mut();
+        match unsafe { ffi::qoa_decode_plan_from_clips(c.as_ptr(), c.len(), &mut h) } {
+            0 => Ok(Self { h, streams: Vec::new() }),
+            e => Err(dec_err(e)),
+        }
+    }
+    /// Arbitrary QOA streams, parsed on the host the way the reference decoder walks them (:205-289, :320-328); the device
+    /// copy of stream `i` starts at byte `in_offset[i]`, its PCM lands at i16 index `out_offset[i]`.
+    pub fn from_streams(streams: &[&[u8]], in_offset: &[u64], out_offset: &[u64]) -> Result<Self, DecodeError> {
+        if in_offset.len() != streams.len() || out_offset.len() != streams.len() { return Err(DecodeError::InvalidFrameHeader); }
+        let ptrs: Vec<*const u8> = streams.iter().map(|s| s.as_ptr()).collect();
+        let lens: Vec<usize> = streams.iter().map(|s| s.len()).collect();
+        let mut status = vec![0 as c_int; streams.len()];
+        let mut n_out = vec![0u64; streams.len()];
+        let mut h = std::ptr::null_mut();
+        let rc = unsafe {
+            ffi::qoa_decode_plan_from_streams(ptrs.as_ptr(), lens.as_ptr(), in_offset.as_ptr(), out_offset.as_ptr(), streams.len(),
+                                              status.as_mut_ptr(), n_out.as_mut_ptr(), &mut h)
+        };
+        if rc != 0 { return Err(dec_err(rc)); }
+        let streams = n_out.iter().zip(&status).map(|(&n, &s)| (n, if s == 0 { None } else { Some(dec_err(s)) })).collect();
+        Ok(Self { h, streams })
+    }
+    /// `(encoded bytes read, pcm bytes written, i16 samples)` of one run
+    pub fn bytes(&self) -> (u64, u64, u64) {
+        let (mut a, mut b, mut c) = (0u64, 0u64, 0u64);
+        unsafe { ffi::qoa_decode_plan_bytes(self.h, &mut a, &mut b, &mut c) };
+        (a, b, c)
+    }
+    /// # Safety
+    /// `d_in` / `d_out` must be device memory valid for every stream of the plan until the stream has run the launches.
+    pub unsafe fn run(&mut self, d_in: *const u8, d_out: *mut i16, stream: *mut c_void) -> Result<(), DecodeError> {
+        match ffi::qoa_decode_plan_run(self.h, d_in, d_out, stream) { 0 => Ok(()), e => Err(dec_err(e)) }
+    }
+    /// frames whose header on the device disagreed with the plan in the last run (synchronises)
+    pub fn mismatches(&mut self) -> Result<u32, DecodeError> {
+        let mut n = 0u32;
+        match unsafe { ffi::qoa_decode_plan_mismatches(self.h, &mut n) } { 0 => Ok(n), e => Err(dec_err(e)) }
+    }
+}
+impl Drop for DecodePlan {
+    fn drop(&mut self) { unsafe { ffi::qoa_decode_plan_free(self.h) } }
+}
+
+/// The time-sliced host pipeline as a persistent handle (`qoa_host_pipeline_*`): `encode` is `encode_all` per clip from host
+/// PCM to host bytes, `decode` the way back; the slices are bounds-checked against the clip list, so both are safe.
+pub struct HostPipeline {
+    h: *mut ffi::qoa_host_pipeline,
+}
+unsafe impl Send for HostPipeline {}
+
+impl HostPipeline {
+    pub fn new() -> Result<Self, EncodeError> {
+        let mut h = std::ptr::null_mut();
+        match unsafe { ffi::qoa_host_pipeline_create(&mut h) } { 0 => Ok(Self { h }), e => Err(enc_err(e)) }
+    }
+    pub fn encode(&mut self, clips: &[BatchClip], pcm: &[i16], out: &mut [u8], chunk_frames: u32) -> Result<(), EncodeError> {
+        if !clips_fit(clips, pcm.len(), out.len()) { return Err(EncodeError::InvalidSamples); }
+        let c = ffi_clips(clips);
+        match unsafe { ffi::qoa_host_pipeline_encode(self.h, c.as_ptr(), c.len(), pcm.as_ptr(), out.as_mut_ptr(), chunk_frames) } {
+            0 => Ok(()),
+            e => Err(enc_err(e)),
+        }
+    }
+    pub fn decode(&mut self, clips: &[BatchClip], enc: &[u8], pcm: &mut [i16], chunk_frames: u32) -> Result<(), DecodeError> {
+        if !clips_fit(clips, pcm.len(), enc.len()) { return Err(DecodeError::InvalidFrameHeader); }
+        let c = ffi_clips(clips);
+        match unsafe { ffi::qoa_host_pipeline_decode(self.h, c.as_ptr(), c.len(), enc.as_ptr(), pcm.as_mut_ptr(), chunk_frames) } {
+            0 => Ok(()),
+            e => Err(dec_err(e)),
+        }
+    }
+}
+impl Drop for HostPipeline {
+    fn drop(&mut self) { unsafe { ffi::qoa_host_pipeline_free(self.h) } }
+}
+
+/// One-shot forms of `HostPipeline::encode` / `decode` (the handle lives for the call).
+pub fn encode_batch_host(clips: &[BatchClip], pcm: &[i16], out: &mut [u8], chunk_frames: u32) -> Result<(), EncodeError> {
+    if !clips_fit(clips, pcm.len(), out.len()) { return Err(EncodeError::InvalidSamples); }
+    let c = ffi_clips(clips);
+    match unsafe { ffi::qoa_encode_batch_host(c.as_ptr(), c.len(), pcm.as_ptr(), out.as_mut_ptr(), chunk_frames) } {
+        0 => Ok(()),
+        e => Err(enc_err(e)),
+    }
+}
+pub fn decode_batch_host(clips: &[BatchClip], enc: &[u8], pcm: &mut [i16], chunk_frames: u32) -> Result<(), DecodeError> {
+    if !clips_fit(clips, pcm.len(), enc.len()) { return Err(DecodeError::InvalidFrameHeader); }
+    let c = ffi_clips(clips);
+    match unsafe { ffi::qoa_decode_batch_host(c.as_ptr(), c.len(), enc.as_ptr(), pcm.as_mut_ptr(), chunk_frames) } {
+        0 => Ok(()),
+        e => Err(dec_err(e)),
+    }
+}
+
+impl MultiGpu {
+    /// `qoa_multi_create_flags`: `QOA_MULTI_ALLOW_DUPLICATE_DEVICES` (= 1) is a test mode for boxes with fewer GPUs than shards.
+    pub fn with_flags(devices: &[i32], flags: u32) -> Result<Self, EncodeError> {
+        let mut h = std::ptr::null_mut();
+        match unsafe { ffi::qoa_multi_create_flags(devices.as_ptr(), devices.len() as c_int, flags, &mut h) } {
+            0 => Ok(Self { h, n_devices: devices.len() }),
+            c => Err(enc_err(c)),
+        }
+    }
+}
+
+/// `qoa_stream_info`: how the reference decoder's walk over a stream ends (host only, no GPU work).
+#[derive(Debug)]
+pub struct StreamInfo {
+    pub mode: ProcessingMode,
+    /// `None` = clean end, else the error `QoaDecoder::new` or the iterator raises
+    pub terminal: Option<DecodeError>,
+    /// the error is raised by `QoaDecoder::new` itself
+    pub in_new: bool,
+    pub n_frames: u64,
+    pub n_samples: u64,
+}
+pub fn stream_scan(bytes: &[u8]) -> StreamInfo {
+    let mut i = ffi::qoa_stream_info::default();
+    unsafe { ffi::qoa_stream_scan(bytes.as_ptr(), bytes.len(), &mut i) };
+    let mode = if i.mode.kind == 1 { ProcessingMode::Streaming } else {
+        ProcessingMode::FixedSamples { channels: i.mode.channels, sample_rate: i.mode.sample_rate, samples: i.mode.samples } };
+    StreamInfo { mode, terminal: if i.terminal == 0 { None } else { Some(dec_err(i.terminal)) }, in_new: i.in_new != 0,
+                 n_frames: i.n_frames, n_samples: i.n_samples }
 }

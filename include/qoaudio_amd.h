@@ -146,6 +146,8 @@ typedef struct qoa_encode_plan qoa_encode_plan;
 #define QOA_PLAN_NO_WIDE_FORM 16384u     /* debug: no wide form (exact quotient with the true 64-bit rank: full-scale noise); same bytes */
 #define QOA_PLAN_COUNTERS 512u         /* count the fast paths' fall-backs (qoa_encode_plan_stats / _counters); without it the */
                                        /* kernel is handed no counter block and executes no atomic at all */
+#define QOA_PLAN_WAVE_STATS 32768u     /* every compute wavefront records, once, at its exit, how many slices it ran on each step */
+                                       /* form and how long it took (qoa_encode_plan_wave_stats): no atomics, same bytes */
 #define QOA_PLAN_CPW_1 (1u << 4)       /* force chains-per-wavefront = 1 / 2 / 4 (default: 4) */
 #define QOA_PLAN_CPW_2 (2u << 4)
 #define QOA_PLAN_CPW_4 (4u << 4)
@@ -158,10 +160,21 @@ int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint
                           uint64_t *samples_i16);
 /* How the plan's launches are shaped (diagnostics for bench.py): total compute wavefronts over its launches, chains per
  * wavefront of the largest launch, whether that launch takes the LDS-table step form (chosen from 8 wavefronts per SIMD up,
- * or forced by QOA_PLAN_LDS_TABLES), and whether it runs two-wavefront workgroups (a helper wavefront beside every compute
- * wavefront: launches of up to 512 compute wavefronts).  Any pointer may be null. */
+ * or forced by QOA_PLAN_LDS_TABLES).  Any pointer may be null. */
 int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
-                                uint32_t *lds_table_form, uint32_t *helper_wavefronts);
+                                uint32_t *lds_table_form);
+/* The same and more as a struct that can grow: set struct_bytes = sizeof(qoa_launch_shape) before the call.
+ * helper_wavefronts: the largest launch runs two-wavefront workgroups (a helper wavefront beside every compute wavefront:
+ * launches of up to 512 compute wavefronts); launches: kernel launches per run (one per channel count in the batch). */
+typedef struct qoa_launch_shape {
+    uint32_t struct_bytes;
+    uint32_t wavefronts;
+    uint32_t chains_per_wavefront;
+    uint32_t lds_table_form;
+    uint32_t helper_wavefronts;
+    uint32_t launches;
+} qoa_launch_shape;
+int qoa_encode_plan_launch_shape(const qoa_encode_plan *plan, qoa_launch_shape *shape);
 /* Enqueue the encode of the whole batch on `stream` (a hipStream_t, may be NULL).  d_pcm and
  * d_out are DEVICE pointers.  Asynchronous: returns after the launch. */
 int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream);
@@ -191,6 +204,38 @@ int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint
  *          full form, out[9] (wavefront, slice) pairs it settled.
  * Entries beyond the last counter read 0. */
 int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n);
+
+/* What a batch cost, wavefront by wavefront (plans created with QOA_PLAN_WAVE_STATS; the LAST run's records; synchronises
+ * the device).  K1's speed depends on the material: a slice runs on the cheapest step form whose exactness the kernel can
+ * prove for it (src/lib.rs:516-593 is the search being reproduced; :613-617 the quotient that wraps at scalefactors 0 / 1 on
+ * loud material, :823-826 the weights that hard-clipped input drives out of the i16 range), a wavefront is as slow as the
+ * forms its four chains need, and a batch takes as long as its slowest wavefront.  Forms, cheapest first:
+ *   0 cheap-quotient speculative   1 exact-quotient speculative (or LDS-table)   2 penalty   3 wide (64-bit rank)
+ *   4 full packed   5 32-bit block statement   6 one-slice statements (tail slices, ragged blocks)   7 blocks (not slices)
+ * slices[f] counts wavefront-slices ATTEMPTED on form f (a slice a form declines is counted there and on the form that took
+ * it over).  issue_slots[f] is the instruction count of one slice on that form, cycles_per_issue what a lone wavefront pays
+ * per instruction (4.06) and loop_overhead what a block loop costs beyond its steps (barrier, dispatch, loop branch, the
+ * winner's LDS round trip: 5-10 %, taken as 1.10): ordinary music costs about 519 x 4.06 x 1.10 = 2,320 cycles per slice, and
+ * no input should cost more than bound_cycles_per_slice = 842 x 4.06 x 1.10 = 3,760 (every slice on the 32-bit statement):
+ * clipped material runs at most ~1.6x slower than music.  cycles_per_slice_* are measured (s_memtime around the wavefront's
+ * whole life / slices of its longest chain); slowest_* describe the wavefront with the highest measured figure. */
+#define QOA_WAVE_FORMS 8
+typedef struct qoa_wave_stats {
+    uint32_t struct_bytes;                     /* in: sizeof(qoa_wave_stats) */
+    uint32_t wavefronts;                       /* compute wavefronts that ran slices */
+    uint64_t slices[QOA_WAVE_FORMS];
+    uint32_t issue_slots[QOA_WAVE_FORMS];
+    double cycles_per_issue;
+    double loop_overhead;
+    double bound_cycles_per_slice;
+    double cycles_per_slice_min, cycles_per_slice_p50, cycles_per_slice_max;
+    uint32_t slowest_wavefront;                /* index over the plan's launches in order */
+    uint32_t slowest_channels;                 /* channel count of its launch */
+    uint32_t slowest_slices_of_chain;          /* slices of its longest chain */
+    uint32_t slowest_slices[QOA_WAVE_FORMS];   /* its form mix */
+    double slowest_predicted_cycles_per_slice; /* sum(slowest_slices x issue_slots) x cycles_per_issue x loop_overhead / slices */
+} qoa_wave_stats;
+int qoa_encode_plan_wave_stats(qoa_encode_plan *plan, qoa_wave_stats *out);
 
 /* ---- batch encode on HOST-resident buffers: time-sliced pipeline ----
  * Semantically encode_all per clip (src/lib.rs:760-763) with h_pcm / h_out in host memory (pinned memory makes

@@ -18,7 +18,7 @@ SYMBOLS = [
     "qoa_encoded_size", "qoa_frame_size",
     "qoa_encoder_new", "qoa_encoder_free", "qoa_encoder_encode", "qoa_encoder_write_header",
     "qoa_encoder_encode_frame", "qoa_encoder_get_lms", "qoa_encoder_set_lms", "qoa_debug_encode_slice", "qoa_debug_encoder_set_plan_flags", "qoa_encode_all",
-    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_launch_info", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
+    "qoa_encode_plan_create", "qoa_encode_plan_free", "qoa_encode_plan_bytes", "qoa_encode_plan_run", "qoa_encode_plan_launch_info", "qoa_encode_plan_launch_shape", "qoa_encode_plan_wave_stats", "qoa_encode_plan_stats", "qoa_encode_plan_counters",
     "qoa_encode_batch_host", "qoa_host_pipeline_create", "qoa_host_pipeline_free", "qoa_host_pipeline_encode",
     "qoa_host_pipeline_decode", "qoa_decode_batch_host",
     "qoa_multi_create", "qoa_multi_create_flags", "qoa_multi_free", "qoa_multi_shard", "qoa_multi_encode", "qoa_multi_decode",
@@ -37,6 +37,24 @@ class Desc(C.Structure):
 
 class Clip(C.Structure):
     _fields_ = [("pcm_offset", C.c_uint64), ("out_offset", C.c_uint64), ("desc", Desc)]
+
+
+class LaunchShape(C.Structure):  # qoa_launch_shape
+    _fields_ = [("struct_bytes", C.c_uint32), ("wavefronts", C.c_uint32), ("chains_per_wavefront", C.c_uint32),
+                ("lds_table_form", C.c_uint32), ("helper_wavefronts", C.c_uint32), ("launches", C.c_uint32)]
+
+
+WAVE_FORMS = 8
+WAVE_FORM_NAMES = ("cheap_quotient", "exact_quotient", "penalty", "wide", "full_packed", "block_32bit", "one_slice", "blocks")
+
+
+class WaveStats(C.Structure):  # qoa_wave_stats
+    _fields_ = [("struct_bytes", C.c_uint32), ("wavefronts", C.c_uint32), ("slices", C.c_uint64 * WAVE_FORMS),
+                ("issue_slots", C.c_uint32 * WAVE_FORMS), ("cycles_per_issue", C.c_double), ("loop_overhead", C.c_double),
+                ("bound_cycles_per_slice", C.c_double),
+                ("cycles_per_slice_min", C.c_double), ("cycles_per_slice_p50", C.c_double), ("cycles_per_slice_max", C.c_double),
+                ("slowest_wavefront", C.c_uint32), ("slowest_channels", C.c_uint32), ("slowest_slices_of_chain", C.c_uint32),
+                ("slowest_slices", C.c_uint32 * WAVE_FORMS), ("slowest_predicted_cycles_per_slice", C.c_double)]
 
 
 class FrameHeader(C.Structure):
@@ -64,7 +82,7 @@ def build(force=False):
     """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
-    subprocess.check_call(["make", "-s", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
     return LIB_PATH
 
 
@@ -114,8 +132,9 @@ def lib():
     L.qoa_encode_plan_free.restype = None
     L.qoa_encode_plan_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_run.argtypes = [vp, vp, vp, vp]
-    L.qoa_encode_plan_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
-                                              C.POINTER(C.c_uint32)]
+    L.qoa_encode_plan_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.qoa_encode_plan_launch_shape.argtypes = [vp, C.POINTER(LaunchShape)]
+    L.qoa_encode_plan_wave_stats.argtypes = [vp, C.POINTER(WaveStats)]
     L.qoa_encode_plan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qoa_encode_plan_counters.argtypes = [vp, C.POINTER(C.c_uint64), sz]
     L.qoa_encode_batch_host.argtypes = [C.POINTER(Clip), sz, vp, vp, C.c_uint32]

@@ -25,6 +25,7 @@ PLAN_NO_BLOCK32 = 2048
 PLAN_NO_HELPER = 4096
 PLAN_FORCE_HELPER = 8192
 PLAN_NO_WIDE_FORM = 16384
+PLAN_WAVE_STATS = 32768  # per-wavefront form counts and cycles, written once at each wavefront's exit (EncodePlan.wave_stats)
 PLAN_COUNTERS = 512  # count the fast paths' fall-backs (EncodePlan.stats / .counters); off by default: no atomics in the kernel
 PLAN_CPW_1, PLAN_CPW_2, PLAN_CPW_4 = 1 << 4, 2 << 4, 4 << 4
 MULTI_ALLOW_DUPLICATE_DEVICES = 1
@@ -87,10 +88,32 @@ class EncodePlan:
         return self.launch_shape()[:3]
 
     def launch_shape(self) -> Tuple[int, int, bool, bool]:
-        """launch_info() + whether the largest launch runs helper wavefronts (qoa_encode_plan_launch_info)."""
-        a, b, c, d = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-        _lib.lib().qoa_encode_plan_launch_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
-        return a.value, b.value, bool(c.value), bool(d.value)
+        """launch_info() + whether the largest launch runs helper wavefronts (qoa_encode_plan_launch_shape)."""
+        sh = _lib.LaunchShape()
+        sh.struct_bytes = C.sizeof(sh)
+        rc = _lib.lib().qoa_encode_plan_launch_shape(self._h, C.byref(sh))
+        if rc:
+            raise EncodeError(rc)
+        return sh.wavefronts, sh.chains_per_wavefront, bool(sh.lds_table_form), bool(sh.helper_wavefronts)
+
+    def wave_stats(self) -> dict:
+        """What the LAST run cost wavefront by wavefront (plans created with PLAN_WAVE_STATS; qoa_encode_plan_wave_stats):
+        wavefront-slices per step form, measured cycles per slice (min / p50 / max over wavefronts), the slowest wavefront's
+        form mix with the cycles that mix predicts, and the bound no input can exceed."""
+        ws = _lib.WaveStats()
+        ws.struct_bytes = C.sizeof(ws)
+        rc = _lib.lib().qoa_encode_plan_wave_stats(self._h, C.byref(ws))
+        if rc:
+            raise EncodeError(rc)
+        names = _lib.WAVE_FORM_NAMES
+        return {"wavefronts": ws.wavefronts, "slices": {n: int(v) for n, v in zip(names, ws.slices)},
+                "issue_slots": {n: int(v) for n, v in zip(names, ws.issue_slots)}, "cycles_per_issue": ws.cycles_per_issue,
+                "loop_overhead": ws.loop_overhead, "bound_cycles_per_slice": ws.bound_cycles_per_slice,
+                "cycles_per_slice": {"min": ws.cycles_per_slice_min, "p50": ws.cycles_per_slice_p50, "max": ws.cycles_per_slice_max},
+                "slowest_wavefront": {"index": ws.slowest_wavefront, "channels": ws.slowest_channels,
+                                      "slices_of_chain": ws.slowest_slices_of_chain,
+                                      "form_mix": {n: int(v) for n, v in zip(names, ws.slowest_slices)},
+                                      "predicted_cycles_per_slice": ws.slowest_predicted_cycles_per_slice}}
 
     def stats(self) -> Tuple[int, int, int]:
         """(declined, unpacked, speculation_misses): slices the kernel's fast paths handed to a slower form, summed over

@@ -142,6 +142,7 @@ struct EncGroup {
     unsigned n = 0;
     DevBuf chains;
     DevBuf lms;
+    DevBuf wave_rec; // QOA_PLAN_WAVE_STATS: kWaveRecWords x u32 per compute wavefront, written by the last run
 };
 
 #if defined(QOA_LAB_HWID)
@@ -218,8 +219,14 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
         g->nch = nch;
         g->n = (unsigned)v.size();
         g->cpw = pick_cpw(v.size(), flags);
+        if ((flags & QOA_PLAN_WAVE_STATS) && g->cpw != 4) {
+            delete plan;
+            return fail_msg("QOA_PLAN_WAVE_STATS needs the default packing (no QOA_PLAN_CPW_1 / _2)", QOA_ENCODE_IO_ERROR);
+        }
         hipError_t e = g->chains.reserve(v.size() * sizeof(EncChain));
         if (e == hipSuccess) e = g->lms.reserve(v.size() * 8 * sizeof(int32_t));
+        if (e == hipSuccess && (flags & QOA_PLAN_WAVE_STATS))
+            e = g->wave_rec.reserve((size_t)((v.size() + 3) / 4) * kWaveRecWords * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(g->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             delete plan;
@@ -258,22 +265,38 @@ static unsigned plan_kernel_flags(uint32_t pf) {
            ((pf & QOA_PLAN_NO_WIDE_FORM) ? 1024u : 0u);
 }
 
-extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
-                                           uint32_t *lds_table_form, uint32_t *helper_wavefronts) {
-    if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
-    uint32_t waves = 0, cpw = 0, lds = 0, helper = 0, biggest = 0;
+extern "C" int qoa_encode_plan_launch_shape(const qoa_encode_plan *plan, qoa_launch_shape *shape) {
+    if (!plan || !shape) return fail_msg("null plan / shape", QOA_ENCODE_IO_ERROR);
+    if (shape->struct_bytes < sizeof(qoa_launch_shape)) return fail_msg("qoa_launch_shape.struct_bytes too small", QOA_ENCODE_IO_ERROR);
+    uint32_t waves = 0, cpw = 0, lds = 0, helper = 0, biggest = 0, launches = 0;
     for (auto *g : plan->groups) {
         const uint32_t w = (g->n + g->cpw - 1) / g->cpw;
         waves += w;
+        launches++;
         if (w > biggest) {
             biggest = w; cpw = (uint32_t)g->cpw; lds = plan_lds_form(plan->flags, g) ? 1u : 0u;
             helper = encode_launch_has_helper(g->cpw, g->n, plan_kernel_flags(plan->flags)) ? 1u : 0u;
         }
     }
-    if (wavefronts) *wavefronts = waves;
-    if (chains_per_wavefront) *chains_per_wavefront = cpw;
-    if (lds_table_form) *lds_table_form = lds;
-    if (helper_wavefronts) *helper_wavefronts = helper;
+    shape->wavefronts = waves;
+    shape->chains_per_wavefront = cpw;
+    shape->lds_table_form = lds;
+    shape->helper_wavefronts = helper;
+    shape->launches = launches;
+    return QOA_OK;
+}
+
+// (the four-pointer form of rounds 1-3; round 4 had added a fifth out-parameter in place -- an ABI break for C callers,
+// advisor round 4 -- which now lives in qoa_launch_shape)
+extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
+                                           uint32_t *lds_table_form) {
+    qoa_launch_shape sh;
+    sh.struct_bytes = sizeof sh;
+    int rc = qoa_encode_plan_launch_shape(plan, &sh);
+    if (rc) return rc;
+    if (wavefronts) *wavefronts = sh.wavefronts;
+    if (chains_per_wavefront) *chains_per_wavefront = sh.chains_per_wavefront;
+    if (lds_table_form) *lds_table_form = sh.lds_table_form;
     return QOA_OK;
 }
 
@@ -286,9 +309,12 @@ extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, 
     const unsigned kflags = 2u | plan_kernel_flags(plan->flags);
     for (auto *g : plan->groups) {
         const unsigned lds = plan_lds_form(plan->flags, g) ? 16u : 0u;
+        if (g->wave_rec.p) // (records of the LAST run: zeroed on the same stream, ahead of the launch that writes them)
+            HIP_TRY(hipMemsetAsync(g->wave_rec.p, 0, (size_t)((g->n + 3) / 4) * kWaveRecWords * sizeof(uint32_t), (hipStream_t)stream),
+                    QOA_ENCODE_IO_ERROR);
         HIP_TRY(launch_encode(g->cpw, g->nch, d_pcm, d_out, (const EncChain *)g->chains.p, g->n, (int32_t *)g->lms.p,
                               kflags | lds, (plan->flags & QOA_PLAN_COUNTERS) ? (unsigned long long *)plan->stats.p : nullptr,
-                              (hipStream_t)stream),
+                              (hipStream_t)stream, (unsigned *)g->wave_rec.p),
                 QOA_ENCODE_IO_ERROR);
     }
     return QOA_OK;
@@ -314,6 +340,68 @@ extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, si
     HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpy(h.data(), plan->stats.p, kCounters * sizeof(uint64_t), hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
     for (size_t i = 0; i < n; i++) out[i] = i < kCounters ? h[i] : 0;
+    return QOA_OK;
+}
+
+// Issue slots per slice of each step form's block loop as tools/gen_slice_asm.py generates it (the cheap-quotient
+// loop 519, exact-quotient speculative 598 (the LDS-table form 477 + 26 LDS reads is reported in the same column), penalty 586,
+// wide 664, full packed 784, 32-bit block statement 842, the one-slice statements ~1,100 with their ds_bpermute exchange), and
+// what a lone wavefront pays per issued instruction (tools/ubench/execmask.hip: 4.06 cycles).  A slice therefore costs between
+// 519 x 4.06 and 842 x 4.06 cycles in the block loops: clipped material, whose chains keep their weights beyond the i16
+// window, is bounded by the 32-bit statement's rate, 1.62x the cheap form's.
+static const uint32_t kFormIssueSlots[QOA_WAVE_FORMS] = {519, 598, 586, 664, 784, 842, 1100, 0};
+static const double kCyclesPerIssue = 4.06;
+// what a block loop costs beyond its steps' issue slots -- the per-block barrier and dispatch, the taken loop branch, the
+// winner's LDS round trip: measured 5 % (32-bit statement) to 10 % (cheap-quotient form) of a slice (profiles/r05_k1_slack.md)
+static const double kLoopOverhead = 1.10;
+
+extern "C" int qoa_encode_plan_wave_stats(qoa_encode_plan *plan, qoa_wave_stats *out) {
+    if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
+    if (!(plan->flags & QOA_PLAN_WAVE_STATS)) return fail_msg("plan was created without QOA_PLAN_WAVE_STATS", QOA_ENCODE_IO_ERROR);
+    if (out->struct_bytes < sizeof(qoa_wave_stats)) return fail_msg("qoa_wave_stats.struct_bytes too small", QOA_ENCODE_IO_ERROR);
+    HIP_TRY(hipDeviceSynchronize(), QOA_ENCODE_IO_ERROR); // the run may be in flight on any stream; this is a diagnostic
+    const uint32_t keep = out->struct_bytes;
+    memset(out, 0, sizeof *out);
+    out->struct_bytes = keep;
+    for (int k = 0; k < QOA_WAVE_FORMS; k++) out->issue_slots[k] = kFormIssueSlots[k];
+    out->cycles_per_issue = kCyclesPerIssue;
+    out->loop_overhead = kLoopOverhead;
+    out->bound_cycles_per_slice = kFormIssueSlots[5] * kCyclesPerIssue * kLoopOverhead;
+    std::vector<double> cps;
+    double worst = -1.0;
+    uint32_t index = 0;
+    for (auto *g : plan->groups) {
+        const size_t waves = (g->n + 3) / 4;
+        std::vector<uint32_t> h(waves * kWaveRecWords);
+        HIP_TRY(hipMemcpy(h.data(), g->wave_rec.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
+        for (size_t w = 0; w < waves; w++, index++) {
+            const uint32_t *r = &h[w * kWaveRecWords];
+            if (!r[kWaveRecForms + 3] || !r[kWaveRecForms + 2]) continue; // no record (an empty time slice), or no slices
+            out->wavefronts++;
+            for (int k = 0; k < QOA_WAVE_FORMS; k++) out->slices[k] += r[k];
+            const double cycles = (double)(((uint64_t)r[kWaveRecForms + 1] << 32) | r[kWaveRecForms]);
+            const double per = cycles / (double)r[kWaveRecForms + 2];
+            cps.push_back(per);
+            if (per > worst) {
+                worst = per;
+                out->slowest_wavefront = index;
+                out->slowest_channels = (uint32_t)g->nch;
+                out->slowest_slices_of_chain = r[kWaveRecForms + 2];
+                double pred = 0;
+                for (int k = 0; k < QOA_WAVE_FORMS; k++) {
+                    out->slowest_slices[k] = r[k];
+                    pred += (double)r[k] * kFormIssueSlots[k] * kCyclesPerIssue * kLoopOverhead;
+                }
+                out->slowest_predicted_cycles_per_slice = pred / (double)r[kWaveRecForms + 2];
+            }
+        }
+    }
+    if (!cps.empty()) {
+        std::sort(cps.begin(), cps.end());
+        out->cycles_per_slice_p50 = cps[cps.size() / 2];
+        out->cycles_per_slice_max = cps.back();
+        out->cycles_per_slice_min = cps.front();
+    }
     return QOA_OK;
 }
 

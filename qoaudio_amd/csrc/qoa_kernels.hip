@@ -596,7 +596,7 @@ constexpr int kSliceDwords = 12;
 constexpr int kTileInts = (kBlockSlices + 1) * kSliceDwords;
 
 // Where lanes whose slice is not wholly inside the clip point their prefetch (20 samples x 8 channels of zeros).
-__device__ unsigned short g_prefetch_pad[20 * 8]; // (zero-initialised; not const: a constant-address-space pointer would turn the loads into flat ones)
+static __device__ unsigned short g_prefetch_pad[20 * 8]; // (zero-initialised; not const: a constant-address-space pointer would turn the loads into flat ones)
 
 // Prefetch of one slice per lane, a block ahead: 20 loads off ONE address (sample t of this channel is p[t * NCH]: the
 // offsets are immediates), nothing per sample but the load.  Round 2 clamped every sample's index to the clip's last
@@ -680,11 +680,16 @@ __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt
 // kernel: tools/k1lab, QOA_LAB_NO_BLOCKTOP on the periodic class).  Barrier b separates the compute wavefront's blocks
 // b - 1 and b: before it the helper has filled tile[b & 1] and flushed out_tile[b & 1] (block b - 2's words); after it the
 // helper flushes out_tile[(b - 1) & 1], fills tile[(b + 1) & 1] and writes frame b / 16's header.
-template <int CPW, int NCH, bool HELPER = false>
+//
+// REC = true (plans created with QOA_PLAN_WAVE_STATS): the same kernel with eight wave-uniform counters -- wavefront-slices
+// per step form, counted where the ladder hands blocks out -- and a cycle count; lane 0 of every compute wavefront writes
+// them to wave_rec[wave * kWaveRecWords ..] once, at exit.  No atomics, nothing on the slice path; a separate instantiation,
+// so the kernel every other plan runs is the same code as before (qoa_kernels.h: kWaveRec*).
+template <int CPW, int NCH, bool HELPER = false, bool REC = false>
 __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restrict__ pcm, uint8_t *__restrict__ out,
                                                          const EncChain *__restrict__ chains, unsigned n_chains,
                                                          int32_t *__restrict__ lms_state, unsigned flags,
-                                                         unsigned long long *__restrict__ stats) {
+                                                         unsigned long long *__restrict__ stats, unsigned *__restrict__ wave_rec) {
     // sample tiles [wave][chain][kTileInts]
     __shared__ __attribute__((aligned(16))) int s_smp[4 * CPW * kTileInts];
     // candidate end states of the slice in flight; two buffers: the speculative loop alternates between them so that
@@ -736,7 +741,13 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     // 0 cheap, 1 exact-quotient speculative, 2 penalty, 3 wide, 4 full packed, 5 32-bit block, 6 slice loop, 7 blocks
 #define QOA_LAB_FORM(k, n) do { if (stats && lane == 0 && wave < 2048u) stats[10 + 4096 + 2048 + wave * 8u + (k)] += (unsigned long long)(n); } while (0)
 #else
-#define QOA_LAB_FORM(k, n) do { } while (0)
+    // REC: wavefront-slices ATTEMPTED per form (a declined slice counts on the form that declined it too):
+    // 0 cheap-quotient, 1 exact-quotient speculative (or the LDS-table form), 2 penalty, 3 wide, 4 full packed, 5 32-bit block
+    // statement, 6 one-slice statements (tail slices, ragged blocks), 7 blocks
+    unsigned rec_cnt[kWaveRecForms] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)rec_cnt;
+    const unsigned long long rec_t0 = REC ? __builtin_readcyclecounter() : 0ull;
+#define QOA_LAB_FORM(k, n) do { if constexpr (REC) rec_cnt[k] += (unsigned)__builtin_amdgcn_readfirstlane((int)(n)); } while (0)
 #endif
     const int sf = (int)(lane & 15u);
     const unsigned row_base = lane & ~15u;
@@ -953,6 +964,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                     if (lds_tables) {
                         j = run_block_spec_ldsq(tile0, cand_addr, kCandBufBytes, outb_addr, dummy_addr, sf, kc, limq, winq, qtab_addr,
                                                 kBlockSlices, pk);
+                        QOA_LAB_FORM(1, j + (j < kBlockSlices ? 1u : 0u));
                     } else {
                         // cheap quotient first; a slice it declines is repeated with the exact quotient and the cheap form takes
                         // the block up again behind it -- unless declines come in quick succession (a loud passage)
@@ -962,14 +974,14 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
                             if (cheap) {
                                 if (!cheap_declined) {
                                     unsigned marked = 0;
+                                    const unsigned j_was = j; // (the per-wavefront counts)
+                                    (void)j_was;
                                     if (stats)
                                         j += run_block_spec<true, true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
                                                                         dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk, &marked);
                                     else
                                         j += run_block_spec<true>(tile0 + 4u * kSliceDwords * j, cand_addr, kCandBufBytes, outb_addr + 8u * j,
                                                                   dummy_addr, sf, kc, limq, winq, kBlockSlices - j, pk);
-                                    const unsigned j_was = j;
-                                    (void)j_was; // (the lab's per-wavefront counts)
                                     j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
                                     if (stats && marked) atomicAdd(&stats[4], (unsigned long long)marked);
                                     QOA_LAB_FORM(0, j - j_was + (j < kBlockSlices ? 1u : 0u));
@@ -1132,6 +1144,19 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
     }
 #ifdef QOA_LAB_HWID
     if (stats && lane == 0 && wave < 2048u) stats[10 + 4096 + wave] = __builtin_readcyclecounter() - hwid_t0;
+#else
+    if constexpr (REC) {
+        if (lane == 0 && wave_rec) { // (lane 0 = the wave's first chain: the longest one, clips are handed out longest first)
+            const unsigned long long dt = __builtin_readcyclecounter() - rec_t0;
+            unsigned *r = wave_rec + (size_t)wave * kWaveRecWords;
+#pragma unroll
+            for (int k = 0; k < kWaveRecForms; k++) r[k] = rec_cnt[k];
+            r[kWaveRecForms] = (unsigned)dt;
+            r[kWaveRecForms + 1] = (unsigned)(dt >> 32);
+            r[kWaveRecForms + 2] = nslices;
+            r[kWaveRecForms + 3] = 1u; // record valid
+        }
+    }
 #endif
     if (packed) pk_unpack(pk, st);
     if (sf == 0) {
@@ -1148,6 +1173,7 @@ __global__ void __launch_bounds__(256) qoa_encode_kernel(const int16_t *__restri
 #endif
 }
 
+#ifndef QOA_REC_TU // (qoa_kernels_rec.hip compiles this file again for the recording instantiations alone: see the launchers)
 // ------------------------------------------------------------------------------------------------
 // Test hook: one slice, all 16 candidates, through the very same device functions as K1.  Returns every
 // candidate's total rank, first-sample rank, packed slice and end state so that tests can compare the
@@ -1210,9 +1236,15 @@ __global__ void qoa_debug_slice_kernel(const int32_t *__restrict__ state, const 
     o[0] = r.lms.h0; o[1] = r.lms.h1; o[2] = r.lms.h2; o[3] = r.lms.h3;
     o[4] = r.lms.w0; o[5] = r.lms.w1; o[6] = r.lms.w2; o[7] = r.lms.w3;
 }
+#endif // QOA_REC_TU
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
+//
+// The recording instantiations (REC = true: 8 channel counts x with / without helper wavefronts, default packing only) are
+// compiled in a translation unit of their own, qoa_kernels_rec.hip = this file with QOA_REC_TU defined: they take hipcc as
+// long again as everything else in here, and make builds the two objects side by side.
 // ------------------------------------------------------------------------------------------------
+#ifndef QOA_REC_TU
 bool encode_launch_has_helper(int cpw, unsigned n, unsigned flags) {
     // A launch that leaves at least half of the chip's 1024 SIMDs idle gives every compute wavefront a helper wavefront
     // (HELPER workgroups: see the kernel).  flags bit 8: never, bit 9: always (tests, experiments).
@@ -1220,9 +1252,11 @@ bool encode_launch_has_helper(int cpw, unsigned n, unsigned flags) {
     return (flags & 256u) == 0 && (waves <= kHelperMaxWaves || (flags & 512u) != 0);
 }
 
-template <int CPW>
+#endif // (qoa_kernels_rec.hip calls the main object's copy)
+
+template <int CPW, bool REC = false>
 static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
-                                    int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream) {
+                                    int32_t *lms, unsigned flags, unsigned long long *stats, unsigned *wave_rec, hipStream_t stream) {
     // Fewer wavefronts than one workgroup holds (a single mono / stereo / 3-channel clip): one wavefront per workgroup, so that
     // each lands on a compute unit of its own.  Two wavefronts of one partly filled 4-wave workgroup sometimes end up on the
     // same SIMD, where they share the issue port: the same single-clip encode took 160 or 340 ms (round-1 verdict, weak #9;
@@ -1234,7 +1268,7 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
             dim3 g(waves), b(128);
 #define QOA_LAUNCH(N)                                                                                                    \
     case N:                                                                                                              \
-        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N, true>), g, b, 0, stream, pcm, out, chains, n, lms, flags, stats); \
+        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N, true, REC>), g, b, 0, stream, pcm, out, chains, n, lms, flags, stats, wave_rec); \
         break;
             switch (nch) {
                 QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
@@ -1249,7 +1283,7 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
     dim3 g(blocks), b(64 * kWavesPerBlock);
 #define QOA_LAUNCH(N)                                                                                              \
     case N:                                                                                                        \
-        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N>), g, b, 0, stream, pcm, out, chains, n, lms, flags, stats); \
+        hipLaunchKernelGGL((qoa_encode_kernel<CPW, N, false, REC>), g, b, 0, stream, pcm, out, chains, n, lms, flags, stats, wave_rec); \
         break;
     switch (nch) {
         QOA_LAUNCH(1) QOA_LAUNCH(2) QOA_LAUNCH(3) QOA_LAUNCH(4) QOA_LAUNCH(5) QOA_LAUNCH(6) QOA_LAUNCH(7) QOA_LAUNCH(8)
@@ -1259,13 +1293,23 @@ static hipError_t launch_encode_nch(int nch, const int16_t *pcm, uint8_t *out, c
     return hipGetLastError();
 }
 
+#ifdef QOA_REC_TU
+hipError_t launch_encode_rec(int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n, int32_t *lms,
+                             unsigned flags, unsigned long long *stats, unsigned *wave_rec, hipStream_t stream) {
+    return launch_encode_nch<4, true>(nch, pcm, out, chains, n, lms, flags, stats, wave_rec, stream);
+}
+#else
 hipError_t launch_encode(int cpw, int nch, const int16_t *pcm, uint8_t *out, const EncChain *chains, unsigned n,
-                         int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream) {
+                         int32_t *lms, unsigned flags, unsigned long long *stats, hipStream_t stream, unsigned *wave_rec) {
     if (n == 0) return hipSuccess;
+    if (wave_rec) { // the recording instantiations exist for the default packing only (qoa_kernels_rec.hip)
+        if (cpw != 4) return hipErrorInvalidValue;
+        return launch_encode_rec(nch, pcm, out, chains, n, lms, flags, stats, wave_rec, stream);
+    }
     switch (cpw) {
-    case 1: return launch_encode_nch<1>(nch, pcm, out, chains, n, lms, flags, stats, stream);
-    case 2: return launch_encode_nch<2>(nch, pcm, out, chains, n, lms, flags, stats, stream);
-    case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, stats, stream);
+    case 1: return launch_encode_nch<1>(nch, pcm, out, chains, n, lms, flags, stats, nullptr, stream);
+    case 2: return launch_encode_nch<2>(nch, pcm, out, chains, n, lms, flags, stats, nullptr, stream);
+    case 4: return launch_encode_nch<4>(nch, pcm, out, chains, n, lms, flags, stats, nullptr, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1277,5 +1321,6 @@ hipError_t launch_debug_slice(const int32_t *state, const int32_t *samples, int 
                        slice, end_state);
     return hipGetLastError();
 }
+#endif // QOA_REC_TU
 
 } // namespace qoa

@@ -1155,3 +1155,46 @@ def test_plan_packing_keeps_helper_wavefronts_available(gpu):
     assert batch.EncodePlan(clips, batch.PLAN_CPW_4).launch_info()[:2] == (32, 4)
     assert batch.EncodePlan(clips, batch.PLAN_CPW_1).launch_shape() == (128, 1, False, True)
     assert batch.EncodePlan(clips, batch.PLAN_CPW_2).launch_info()[:2] == (64, 2)
+
+
+def test_wave_stats_tell_what_a_batch_cost(gpu, oracle):
+    """QOA_PLAN_WAVE_STATS / qoa_encode_plan_wave_stats (round 5): every compute wavefront records, once, at its exit, the
+    slices it ran per step form and its cycles -- the recording instantiation of K1, no atomics.  Same bytes as the default
+    plan; ordinary music sits on the cheap-quotient form, music amplified into hard clipping reaches the 32-bit block statement
+    (src/lib.rs:613-617, :823-826) and its slowest wavefront stays within the bound the record states; plans that force
+    another packing are refused."""
+    from qoaudio_amd import batch, synth
+    n_clips, ch, frames = 96, 2, 8
+    samples = frames * 5120
+    desc = gpu.QoaDesc(ch, 44100, samples)
+    clips, _, per_enc = batch.uniform_clips(n_clips, desc)
+    music = synth.make_clips(n_clips, samples, ch, 44100, device="cuda:0")
+    loud = (music.to(torch.int32) * 3).clamp_(-32768, 32767).to(torch.int16)
+    for name, pcm in (("music", music), ("loud", loud)):
+        out = torch.zeros((n_clips, per_enc), dtype=torch.uint8, device="cuda")
+        batch.EncodePlan(clips).run(pcm, out)
+        out2 = torch.zeros_like(out)
+        for flags in (batch.PLAN_WAVE_STATS, batch.PLAN_WAVE_STATS | batch.PLAN_NO_HELPER):
+            plan = batch.EncodePlan(clips, flags)
+            plan.run(pcm, out2)
+            plan.run(pcm, out2)  # (the records are the LAST run's, not a sum)
+            ws = plan.wave_stats()
+            assert torch.equal(out, out2), (name, flags)
+            assert ws["wavefronts"] == n_clips * ch // 4
+            total = frames * 256
+            mix = ws["slowest_wavefront"]["form_mix"]
+            assert ws["slices"]["blocks"] == ws["wavefronts"] * frames * 16 and mix["blocks"] == frames * 16
+            done = sum(v for k, v in ws["slices"].items() if k != "blocks")
+            assert ws["wavefronts"] * total <= done <= ws["wavefronts"] * total * 1.25, (name, ws)  # (declined attempts count twice)
+            cps = ws["cycles_per_slice"]
+            assert 1500 < cps["min"] <= cps["p50"] <= cps["max"] < 1.1 * ws["bound_cycles_per_slice"], (name, cps)
+            if name == "music":
+                assert ws["slices"]["cheap_quotient"] > 0.98 * ws["wavefronts"] * total and ws["slices"]["block_32bit"] == 0
+            else:
+                assert ws["slices"]["block_32bit"] > 0 and cps["max"] > 1.2 * cps["min"]
+        k = n_clips // 2
+        assert out[k].cpu().numpy().tobytes() == oracle.encode_all(pcm[k].cpu().numpy().reshape(-1), ch, 44100, samples)
+    with pytest.raises(gpu.EncodeError):
+        batch.EncodePlan(clips, batch.PLAN_WAVE_STATS | batch.PLAN_CPW_2)
+    with pytest.raises(gpu.EncodeError):
+        batch.EncodePlan(clips).wave_stats()
