@@ -219,12 +219,16 @@ class QoaDecoder:
         self._h = C.c_void_p(None)
         self._reader = None
         self._owned = None        # a file this object opened itself (QoaDecoder.open): closed with the decoder
-        self._read_error = None   # what the reader raised (any exception): an I/O error of the stream, src/lib.rs:889-893
+        # what the reader raised (any exception): an I/O error of the stream, src/lib.rs:889-893.  A one-element holder that
+        # the callback closes over instead of `self`: self -> _cb -> _pull -> self would be a reference cycle, the decoder
+        # reclaimed only by the cyclic collector and a file opened by QoaDecoder.open() closed whenever that runs
+        self._read_error_box = [None]
         L = _lib.lib()
         if _streaming:
             rc = L.qoa_decoder_new_streaming(C.byref(self._h))
         elif hasattr(reader, "read"):
             self._reader = reader
+            box = self._read_error_box
 
             def _pull(_ctx, buf, n):  # qoa_read_fn: bytes stored, 0 at the end, negative for an I/O error
                 try:
@@ -234,7 +238,7 @@ class QoaDecoder:
                     if len(chunk) > n:
                         raise ValueError("reader returned more bytes than asked for")
                 except Exception as e:  # ctypes would swallow it and report 0 = a clean end of stream
-                    self._read_error = e
+                    box[0] = e
                     return -1
                 if not chunk:
                     return 0
@@ -254,7 +258,7 @@ class QoaDecoder:
     def _error(self, rc):
         """DecodeError(rc), chained to the exception the reader raised when that is what it reports."""
         err = DecodeError(rc)
-        cause, self._read_error = self._read_error, None
+        cause, self._read_error_box[0] = self._read_error_box[0], None
         if cause is not None and err.kind == "IoError":
             err.__cause__ = cause
         return err

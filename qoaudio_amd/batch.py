@@ -329,11 +329,13 @@ class MultiGpu:
             pass
 
     def _clips(self, clips):
-        """ctypes image of the clip list; the same list object handed in again (a loop over one batch) is not marshalled
-        again (1024 clips cost ~2 ms of Python per call otherwise)."""
-        sig = (len(clips), clips[0], clips[-1]) if len(clips) else (0,)
-        if self._marshalled is None or self._marshalled[0] is not clips or self._marshalled[2] != sig:
-            self._marshalled = (clips, _clips_array(clips), sig)
+        """ctypes image of the clip list; a list with the same contents handed in again (a loop over one batch) is not
+        marshalled again.  The key is a digest of EVERY entry (offsets and desc), not the list's identity: a caller that
+        edits an entry of the same list in place gets a fresh image (advisor, round 4: the C side would have launched
+        kernels at the stale offsets)."""
+        sig = hash(tuple((po, oo, d.channels, d.sample_rate, d.samples) for po, oo, d in clips))
+        if self._marshalled is None or self._marshalled[0] != (len(clips), sig):
+            self._marshalled = ((len(clips), sig), _clips_array(clips))
         return self._marshalled[1]
 
     def _bases(self, tensors):

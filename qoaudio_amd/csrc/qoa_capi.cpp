@@ -909,38 +909,63 @@ int Walker::walk(const uint8_t *data, size_t len, size_t *pos_io, std::vector<Fr
     }
 }
 
-// Device-side decode tables: frames of 1..8 channels go to K2 (one entry per frame, grouped by channel
-// count); frames with more channels (legal in the format, exotic in practice) go to the generic kernel with
-// one entry per (frame, channel) chain.
+// The general kernel's launches (short last frames of clips, odd alignments) run BESIDE K2u's on a side stream: behind it on
+// the same stream a few hundred short frames kept the chip for a wavefront's lifetime (0.2-0.6 ms) on their own.  One side
+// stream and one event pair serve any number of tables that run on the same caller stream (a pipeline's time slices): a
+// stream-wait captures the event's latest record at the time of the call.
+struct DecSide {
+    hipStream_t s = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DecSide() = default;
+    DecSide(const DecSide &) = delete;
+    DecSide &operator=(const DecSide &) = delete;
+    hipError_t ensure() {
+        hipError_t e = hipSuccess;
+        if (!s) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e == hipSuccess && !ev_fork) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess && !ev_join) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+        return e;
+    }
+    ~DecSide() {
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
+};
+
+// Device-side decode tables: frames of 1..8 channels go to K2u / K2 (one entry per frame, grouped by channel count);
+// frames with more channels (legal in the format, exotic in practice) go to the generic kernel with one entry per
+// (frame, channel) chain.  A table is a VIEW: classify() sorts a slice's records into host vectors, flatten() appends them
+// to one host image, bind() points the table at that image's place in a device buffer.  A decode plan owns one table and
+// its buffers (upload()); the host pipeline keeps the tables of ALL its time slices in one device buffer with one shared
+// counter / sink block and one side stream (advisor, round 4: a 3-minute clip used to cost ~600 hipMalloc / hipFree calls).
 struct DecTables {
-    DevBuf frames[kMaxChannels + 1];
+    const DecChain *d_frames[kMaxChannels + 1] = {nullptr};
     unsigned n_frames[kMaxChannels + 1] = {0};
     bool whole_pieces[kMaxChannels + 1] = {false};
     // K2u (qoa_decode.hip): uniform full frames (256 rows, 5120 sample-times) of 1 .. 8 channels whose PCM sits at a multiple
     // of 4 bytes; everything else stays in frames[] for the general kernel
-    DevBuf uframes[kMaxChannels + 1];
-    // The general kernel's launches (short last frames of clips, odd alignments) run BESIDE K2u's on a side stream: behind it
-    // on the same stream a few hundred short frames kept the chip for a wavefront's lifetime (0.2-0.6 ms) on their own.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const DecChain *d_uframes[kMaxChannels + 1] = {nullptr};
+    unsigned n_uframes[kMaxChannels + 1] = {0};
+    const DecChain *d_chains = nullptr;
+    unsigned n_chains = 0;
+    unsigned *counter_own = nullptr; // [0]: this table's header-mismatch counter
+    uint8_t *sink = nullptr;         // kDecodeScratchBytes: where the general kernel's stores beyond a frame's end go
+    DecSide *side = nullptr;
+
+    // what a single-table owner (a decode plan) holds; the host pipeline's tables leave these empty
+    DevBuf own_records, own_scratch;
+    std::unique_ptr<DecSide> own_side;
+    std::vector<DecChain> own_host;  // source of the asynchronous copy: lives until the next upload
+
     DecTables() = default;
     DecTables(const DecTables &) = delete;
     DecTables &operator=(const DecTables &) = delete;
-    ~DecTables() {
-        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-    }
-    unsigned n_uframes[kMaxChannels + 1] = {0};
-    DevBuf chains;
-    unsigned n_chains = 0;
-    DevBuf mismatch;
 
-    // host copies of what upload() sends: they are the sources of asynchronous copies and live until the next upload
+    // host side of a slice's records, sorted by the kernel that takes them
     std::vector<DecChain> per[kMaxChannels + 1], generic, uni[kMaxChannels + 1];
 
-    // sync = false: the copies are only enqueued on `stream`; the caller must not call upload() again before they ran
-    hipError_t upload(const std::vector<DecChain> &recs, hipStream_t stream, bool sync = true) {
+    size_t classify(const std::vector<DecChain> &recs) {
         for (auto &v : per) v.clear();
         for (auto &v : uni) v.clear();
         generic.clear();
@@ -954,44 +979,69 @@ struct DecTables {
                 generic.push_back(e);
             }
         }
+        size_t total = generic.size();
         for (int n = 1; n <= kMaxChannels; n++) {
-            if (!decode_uniform_group(n)) continue;
-            std::vector<DecChain> rest;
-            for (const DecChain &d : per[n]) {
-                // (K2u's 16-byte stores want a dword-aligned PCM address.  On the 128-byte grid its runs are whole cache lines,
-                // streamed; off it the kernel switches to write-back stores: as streamed stores they ran 1.4-1.6x SLOWER than
-                // the general kernel, 2.07 vs 1.44 ms on 2048 stereo clips x 64 frames)
-                const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 4 == 0;
-                (uniform ? uni[n] : rest).push_back(d);
+            if (decode_uniform_group(n)) {
+                std::vector<DecChain> rest;
+                for (const DecChain &d : per[n]) {
+                    // (K2u's 16-byte stores want a dword-aligned PCM address.  On the 128-byte grid its runs are whole cache
+                    // lines, streamed; off it the kernel switches to write-back stores: as streamed stores they ran 1.4-1.6x
+                    // SLOWER than the general kernel, 2.07 vs 1.44 ms on 2048 stereo clips x 64 frames)
+                    const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 4 == 0;
+                    (uniform ? uni[n] : rest).push_back(d);
+                }
+                per[n].swap(rest); // (K2u's last wave may be short of frames: nothing is left over for a launch of its own)
             }
-            per[n].swap(rest); // (K2u's last wave may be short of frames: nothing is left over for a launch of its own)
-        }
-        const bool fresh = mismatch.p == nullptr;
-        hipError_t e = mismatch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
-        if (e == hipSuccess && (fresh || sync)) e = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
-        for (int n = 1; n <= kMaxChannels && e == hipSuccess; n++) {
             n_uframes[n] = (unsigned)uni[n].size();
-            if (uni[n].empty()) continue;
-            e = uframes[n].reserve(uni[n].size() * sizeof(DecChain));
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(uframes[n].p, uni[n].data(), uni[n].size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
-        }
-        for (int n = 1; n <= kMaxChannels && e == hipSuccess; n++) {
             n_frames[n] = (unsigned)per[n].size();
             whole_pieces[n] = true;
             for (const DecChain &d : per[n]) if (((uint64_t)d.n_out * n * 2) % 16 != 0) whole_pieces[n] = false;
-            if (per[n].empty()) continue;
-            e = frames[n].reserve(per[n].size() * sizeof(DecChain));
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(frames[n].p, per[n].data(), per[n].size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
+            total += uni[n].size() + per[n].size();
         }
         n_chains = (unsigned)generic.size();
-        if (e == hipSuccess && !generic.empty()) {
-            e = chains.reserve(generic.size() * sizeof(DecChain));
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(chains.p, generic.data(), generic.size() * sizeof(DecChain), hipMemcpyHostToDevice, stream);
-        }
-        if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
+        return total;
+    }
+    // appends the classified records to `dst` in bind()'s order and drops the per-kernel host vectors
+    void flatten(std::vector<DecChain> &dst) {
+        for (int n = 1; n <= kMaxChannels; n++) dst.insert(dst.end(), uni[n].begin(), uni[n].end());
+        for (int n = 1; n <= kMaxChannels; n++) dst.insert(dst.end(), per[n].begin(), per[n].end());
+        dst.insert(dst.end(), generic.begin(), generic.end());
+        for (auto &v : per) { v.clear(); v.shrink_to_fit(); }
+        for (auto &v : uni) { v.clear(); v.shrink_to_fit(); }
+        generic.clear(); generic.shrink_to_fit();
+    }
+    // the table's records start at `base` (device memory, flatten()'s order); returns the first record behind them
+    const DecChain *bind(const DecChain *base) {
+        for (int n = 1; n <= kMaxChannels; n++) { d_uframes[n] = base; base += n_uframes[n]; }
+        for (int n = 1; n <= kMaxChannels; n++) { d_frames[n] = base; base += n_frames[n]; }
+        d_chains = base;
+        return base + n_chains;
+    }
+    void set_scratch(void *block, DecSide *shared_side) { // block: 64 + kDecodeScratchBytes of device memory
+        counter_own = (unsigned *)block;
+        sink = (uint8_t *)block + 64;
+        side = shared_side;
+    }
+
+    // single-table form (decode plans): own buffers.  sync = false: the copy is only enqueued on `stream`; the caller must
+    // not call upload() again before it ran
+    hipError_t upload(const std::vector<DecChain> &recs, hipStream_t stream, bool sync = true) {
+        const size_t total = classify(recs);
+        own_host.clear();
+        own_host.reserve(total);
+        flatten(own_host);
+        const bool fresh = own_scratch.p == nullptr;
+        hipError_t e = own_scratch.reserve(64 + kDecodeScratchBytes); // [0]: mismatch counter, [64..]: store sink
+        if (e == hipSuccess && (fresh || sync)) e = hipMemsetAsync(own_scratch.p, 0, sizeof(unsigned), stream);
+        if (e == hipSuccess && total) e = own_records.reserve(total * sizeof(DecChain));
+        if (e == hipSuccess && total)
+            e = hipMemcpyAsync(own_records.p, own_host.data(), total * sizeof(DecChain), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        if (!own_side) own_side.reset(new (std::nothrow) DecSide());
+        if (!own_side) return hipErrorOutOfMemory;
+        bind((const DecChain *)own_records.p);
+        set_scratch(own_scratch.p, own_side.get());
+        if (sync) e = hipStreamSynchronize(stream);
         return e;
     }
     bool empty() const {
@@ -1003,9 +1053,9 @@ struct DecTables {
     // the host pipeline hands all its time slices one counter that adds up over the call)
     hipError_t run(const uint8_t *d_in, int16_t *d_out, hipStream_t stream, unsigned *counter = nullptr) {
         if (!counter) {
-            hipError_t e0 = hipMemsetAsync(mismatch.p, 0, sizeof(unsigned), stream);
+            hipError_t e0 = hipMemsetAsync(counter_own, 0, sizeof(unsigned), stream);
             if (e0 != hipSuccess) return e0;
-            counter = (unsigned *)mismatch.p;
+            counter = counter_own;
         }
         bool has_u = false, has_g = n_chains != 0;
         for (int n = 1; n <= kMaxChannels; n++) { has_u = has_u || n_uframes[n]; has_g = has_g || n_frames[n]; }
@@ -1017,22 +1067,18 @@ struct DecTables {
 #endif
         if (lab_side == 2) has_g = false;
         if (has_u && has_g && lab_side == 1) {
-            hipError_t e = hipSuccess;
-            if (!side) e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-            if (e == hipSuccess && !ev_fork) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-            if (e == hipSuccess && !ev_join) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(ev_fork, stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+            hipError_t e = side->ensure();
+            if (e == hipSuccess) e = hipEventRecord(side->ev_fork, stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side->s, side->ev_fork, 0);
             if (e != hipSuccess) return e;
-            gs = side;
+            gs = side->s;
         }
         for (int n = 1; n <= kMaxChannels && lab_side != 2; n++) {
-            hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, (const DecChain *)frames[n].p, n_frames[n], counter,
-                                                (uint8_t *)mismatch.p + 64, gs);
+            hipError_t e = launch_decode_frames(n, whole_pieces[n], d_in, d_out, d_frames[n], n_frames[n], counter, sink, gs);
             if (e != hipSuccess) return e;
         }
         if (lab_side != 2) {
-            hipError_t e = launch_decode(d_in, d_out, (const DecChain *)chains.p, n_chains, counter, gs);
+            hipError_t e = launch_decode(d_in, d_out, d_chains, n_chains, counter, gs);
             if (e != hipSuccess) return e;
         }
         for (int n = 1; n <= kMaxChannels; n++) {
@@ -1040,14 +1086,13 @@ struct DecTables {
             // K2u stores 16-byte pieces at dword-aligned addresses: with a base pointer off the dword grid (a caller's sub-buffer)
             // the same table goes through the general kernel instead
             hipError_t e = ((uintptr_t)d_out % 4 == 0)
-                               ? launch_decode_uniform(n, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n], counter, stream)
-                               : launch_decode_frames(n, true, d_in, d_out, (const DecChain *)uframes[n].p, n_uframes[n], counter,
-                                                      (uint8_t *)mismatch.p + 64, stream);
+                               ? launch_decode_uniform(n, d_in, d_out, d_uframes[n], n_uframes[n], counter, stream)
+                               : launch_decode_frames(n, true, d_in, d_out, d_uframes[n], n_uframes[n], counter, sink, stream);
             if (e != hipSuccess) return e;
         }
         if (gs != stream) { // join: the caller's stream continues when both are done
-            hipError_t e = hipEventRecord(ev_join, side);
-            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_join, 0);
+            hipError_t e = hipEventRecord(side->ev_join, side->s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, side->ev_join, 0);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -1227,7 +1272,7 @@ extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count
     if (!plan || !count) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
     // the runs may sit on non-blocking side streams, which the null stream's copy below does not wait for
     HIP_TRY(hipDeviceSynchronize(), QOA_DECODE_IO_ERROR);
-    HIP_TRY(hipMemcpy(count, plan->t.mismatch.p, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
+    HIP_TRY(hipMemcpy(count, plan->t.counter_own, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
     return QOA_OK;
 }
 
@@ -1242,8 +1287,10 @@ extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count
 // Layout trusted like qoa_decode_plan_from_clips; every frame header is verified on the device.
 // ------------------------------------------------------------------------------------------------
 struct DecTablesHolder {
-    std::vector<std::unique_ptr<DecTables>> t; // one set per time slice of the batch dec_key describes
-    DevBuf mismatch;                            // header mismatches of the whole call
+    std::vector<std::unique_ptr<DecTables>> t; // one VIEW per time slice of the batch dec_key describes, all of them into ...
+    DevBuf records;                             // ... this one buffer: every slice's frame records, uploaded once
+    DevBuf scratch;                             // [0]: header mismatches of the whole call, [64..): the general kernel's store sink
+    DecSide side;                               // the one side stream the slices' general launches share
 };
 
 qoa_host_pipeline::~qoa_host_pipeline() {
@@ -1323,9 +1370,9 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
     if (!P.dec_key.matches(clips, n_clips, F, src_direct, dst_direct)) {
         P.dec_key.valid = false;
         HIP_TRY(hipStreamSynchronize(P.s_k), QOA_DECODE_IO_ERROR); // (no launch of an earlier call may still read the old tables)
-        HIP_TRY(P.dec->mismatch.reserve(sizeof(unsigned)), QOA_DECODE_IO_ERROR);
+        HIP_TRY(P.dec->scratch.reserve(64 + kDecodeScratchBytes), QOA_DECODE_IO_ERROR);
         P.dec->t.clear();
-        std::vector<DecChain> recs;
+        std::vector<DecChain> recs, all; // all: the records of every time slice, in the order the views are bound below
         for (uint32_t j = 0; j < n_chunks; j++) {
             recs.clear();
             for (size_t i = 0; i < n_clips; i++) {
@@ -1349,12 +1396,22 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
             }
             std::unique_ptr<DecTables> T(new (std::nothrow) DecTables());
             if (!T) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
-            HIP_TRY(T->upload(recs, nullptr), QOA_DECODE_IO_ERROR); // (synchronous: the host copies may go)
+            T->classify(recs);
+            T->flatten(all);
             P.dec->t.push_back(std::move(T));
+        }
+        // ONE allocation and ONE upload for all slices (synchronous: `all` may go); every table is a view into it
+        HIP_TRY(P.dec->records.reserve(std::max<size_t>(all.size(), 1) * sizeof(DecChain)), QOA_DECODE_IO_ERROR);
+        if (!all.empty())
+            HIP_TRY(hipMemcpy(P.dec->records.p, all.data(), all.size() * sizeof(DecChain), hipMemcpyHostToDevice), QOA_DECODE_IO_ERROR);
+        const DecChain *next = (const DecChain *)P.dec->records.p;
+        for (auto &T : P.dec->t) {
+            next = T->bind(next);
+            T->set_scratch(P.dec->scratch.p, &P.dec->side);
         }
         P.dec_key.set(clips, n_clips, F, src_direct, dst_direct);
     }
-    unsigned *const bad_count = (unsigned *)P.dec->mismatch.p;
+    unsigned *const bad_count = (unsigned *)P.dec->scratch.p;
     HIP_TRY(hipMemsetAsync(bad_count, 0, sizeof(unsigned), P.s_k), QOA_DECODE_IO_ERROR);
 
     for (uint32_t j = 0; j < n_chunks + 1; j++) {
