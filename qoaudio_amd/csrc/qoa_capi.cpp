@@ -947,6 +947,11 @@ struct DecTables {
     // of 4 bytes; everything else stays in frames[] for the general kernel
     const DecChain *d_uframes[kMaxChannels + 1] = {nullptr};
     unsigned n_uframes[kMaxChannels + 1] = {0};
+    // The uniform table of a channel count that has the absolute-line variant of K2u (qoa_kernels.h) is ordered
+    // [ odd | on the 128-byte grid | off it ]: the LAST n_uabs[n] frames have a PCM offset off the grid but a multiple of 8 bytes
+    // (the variant's: whole-line streamed stores instead of write-back half lines), the n_ugrid[n] before them an offset on the
+    // grid (either kernel takes them), the first ones ("odd": offsets 4 mod 8) are K2u's alone.
+    unsigned n_uabs[kMaxChannels + 1] = {0}, n_ugrid[kMaxChannels + 1] = {0};
     const DecChain *d_chains = nullptr;
     unsigned n_chains = 0;
     unsigned *counter_own = nullptr; // [0]: this table's header-mismatch counter
@@ -963,11 +968,13 @@ struct DecTables {
     DecTables &operator=(const DecTables &) = delete;
 
     // host side of a slice's records, sorted by the kernel that takes them
-    std::vector<DecChain> per[kMaxChannels + 1], generic, uni[kMaxChannels + 1];
+    std::vector<DecChain> per[kMaxChannels + 1], generic, uni[kMaxChannels + 1], uabs[kMaxChannels + 1], ugrid[kMaxChannels + 1];
 
     size_t classify(const std::vector<DecChain> &recs) {
         for (auto &v : per) v.clear();
         for (auto &v : uni) v.clear();
+        for (auto &v : uabs) v.clear();
+        for (auto &v : ugrid) v.clear();
         generic.clear();
         for (const DecChain &d : recs) {
             if (d.rows == 0 || d.n_out == 0) continue;
@@ -988,10 +995,19 @@ struct DecTables {
                     // lines, streamed; off it the kernel switches to write-back stores: as streamed stores they ran 1.4-1.6x
                     // SLOWER than the general kernel, 2.07 vs 1.44 ms on 2048 stereo clips x 64 frames)
                     const bool uniform = d.rows == kSlicesPerFrame && d.n_out == (uint32_t)kFrameLen && (d.out_off * 2) % 4 == 0;
-                    (uniform ? uni[n] : rest).push_back(d);
+                    const bool abs_n = decode_uniform_abs_supported(n);
+                    const bool off_grid = abs_n && (d.out_off * 2) % 128 != 0 && (d.out_off * 2) % 8 == 0;
+                    const bool on_grid = abs_n && (d.out_off * 2) % 128 == 0;
+                    (!uniform ? rest : off_grid ? uabs[n] : on_grid ? ugrid[n] : uni[n]).push_back(d);
                 }
                 per[n].swap(rest); // (K2u's last wave may be short of frames: nothing is left over for a launch of its own)
             }
+            n_uabs[n] = (unsigned)uabs[n].size();
+            n_ugrid[n] = (unsigned)ugrid[n].size();
+            uni[n].insert(uni[n].end(), ugrid[n].begin(), ugrid[n].end()); // (one table: odd | on the grid | off it)
+            uni[n].insert(uni[n].end(), uabs[n].begin(), uabs[n].end());
+            uabs[n].clear();
+            ugrid[n].clear();
             n_uframes[n] = (unsigned)uni[n].size();
             n_frames[n] = (unsigned)per[n].size();
             whole_pieces[n] = true;
@@ -1058,7 +1074,11 @@ struct DecTables {
             counter = counter_own;
         }
         bool has_u = false, has_g = n_chains != 0;
-        for (int n = 1; n <= kMaxChannels; n++) { has_u = has_u || n_uframes[n]; has_g = has_g || n_frames[n]; }
+        for (int n = 1; n <= kMaxChannels; n++) {
+            has_u = has_u || n_uframes[n];
+            // (the general kernel's frames -- and a handful of K2u-only frames beside an absolute-line launch -- go to the side stream)
+            has_g = has_g || n_frames[n] || (n_uabs[n] && n_uframes[n] - n_uabs[n] - n_ugrid[n] != 0);
+        }
         hipStream_t gs = stream; // where the general kernel's launches go
 #ifdef QOA_LAB_DEC_SIDE_KNOB // (tools/k2lab builds only: 0 = one stream, 2 = skip the general kernel -- wrong PCM, timing experiments)
         static const int lab_side = getenv("QOA_LAB_DEC_SIDE") ? atoi(getenv("QOA_LAB_DEC_SIDE")) : 1;
@@ -1085,9 +1105,25 @@ struct DecTables {
             if (!n_uframes[n]) continue;
             // K2u stores 16-byte pieces at dword-aligned addresses: with a base pointer off the dword grid (a caller's sub-buffer)
             // the same table goes through the general kernel instead
-            hipError_t e = ((uintptr_t)d_out % 4 == 0)
-                               ? launch_decode_uniform(n, d_in, d_out, d_uframes[n], n_uframes[n], counter, stream)
-                               : launch_decode_frames(n, true, d_in, d_out, d_uframes[n], n_uframes[n], counter, sink, stream);
+            hipError_t e = hipSuccess;
+            if ((uintptr_t)d_out % 4 != 0)
+                e = launch_decode_frames(n, true, d_in, d_out, d_uframes[n], n_uframes[n], counter, sink, stream);
+            else if ((uintptr_t)d_out % 128 != 0 || n_uabs[n] == 0)
+                // A base pointer off the grid (a caller's sub-buffer) shifts every frame, and a table without off-grid frames has
+                // nothing for the absolute-line variant: everything through K2u (streamed / write-back stores per wavefront)
+                e = launch_decode_uniform(n, d_in, d_out, d_uframes[n], n_uframes[n], counter, stream);
+            else {
+                // Offsets mean what they say: the off-grid frames go to the absolute-line variant.  The frames ON the grid join
+                // them unless they fill the chip on their own (>= 2048 wavefronts: a K2u launch of their own, which is a few
+                // per cent faster on them): a small launch beside a large one runs alone on the chip for a wavefront's lifetime
+                // (0.2 ms: this very split cost the short-last-frame batches 0.1 ms when it was first built).
+                const unsigned fpw = decode_uniform_group(n);
+                const bool grid_own = (n_ugrid[n] + fpw - 1) / fpw >= 2048u;
+                const unsigned n_k2u = n_uframes[n] - n_uabs[n] - (grid_own ? 0u : n_ugrid[n]);
+                e = launch_decode_uniform(n, d_in, d_out, d_uframes[n], n_k2u, counter, n_k2u * 8u < n_uframes[n] ? gs : stream);
+                if (e == hipSuccess)
+                    e = launch_decode_uniform_abs(n, d_in, d_out, d_uframes[n] + n_k2u, n_uframes[n] - n_k2u, counter, stream);
+            }
             if (e != hipSuccess) return e;
         }
         if (gs != stream) { // join: the caller's stream continues when both are done

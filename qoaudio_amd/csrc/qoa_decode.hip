@@ -459,9 +459,23 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 // -> 4-wave blocks, 12 (stereo) / 8 (mono) waves per CU.  At 4 and 8 channels a round is a single staging unit and a single
 // phase of 640 bytes.
 // ------------------------------------------------------------------------------------------------
-template <int NCH>
+// ABS = true (round 5): the ABSOLUTE-LINE variant for frames whose PCM is off the 128-byte grid (on an 8-byte grid).  The
+// image ring stays frame-relative, but the flush works on the frame's absolute cache lines: a lane's 16-byte piece of line m
+// sits at ring offset (128 m - delta + 16 q) mod RING with delta = (frame's PCM address) mod 128, every store instruction
+// again covers whole lines (streamed), and only the frame's first and last line are partial (masked pieces + one 8-byte
+// store each where delta is no multiple of 16).  What changes against the aligned kernel:
+//  * the ring divides the round's bytes (RING = 320 | 640), so the up to 127 bytes a round leaves behind for the next round's
+//    first line are where that line's pieces look for them; its first 8 bytes are mirrored behind its end (generated rows) so
+//    that a piece that starts 8 bytes before the ring's end is contiguous;
+//  * a line is flushed as soon as it is complete -- whether a phase completes one line or two depends on delta, a per-frame
+//    value -- in TWO store slots per phase that are always issued (static vmcnt bookkeeping), the second under a lane mask;
+//    per-lane state: the round-relative end of the next line (`lend`), from which the ring offset and the address follow.
+// Write-back stores on such frames -- every 128-byte run written as two half lines that meet in L2 -- ran at 0.31 of the HBM
+// peak against 0.42 for the same frames on the grid (bench.py k2_extras.general, round 4).
+template <int NCH, bool ABS = false>
 struct K2uCfg {
     static constexpr bool POW2 = (NCH & (NCH - 1)) == 0; // 1, 2, 4, 8: the channels of a frame fill whole wavefronts
+    static_assert(!ABS || NCH == 2, "absolute-line rows are generated for stereo (tools/gen_decode_asm.py: GEOMETRY_ABS)");
     // bytes per flushed "line" and lanes per line.  128 / 8 everywhere in the product; the lab's mono variant (QOA_K2U_MONO_HALF:
     // 64-byte half lines, a 128-byte ring per frame -> 12 instead of 8 wavefronts per CU) is measured in profiles/r04_k2lab_log.md
 #ifdef QOA_K2U_MONO_HALF
@@ -495,6 +509,11 @@ struct K2uCfg {
     static constexpr int ring() { // whole lines, >= one phase + the largest carried partial line, and a whole number of
                                   // sample-times (2 NCH bytes): a lane's channel offset is added to a wrapped sample-time offset,
                                   // so no sample-time may straddle the ring's end (1 / 2 / 4 / 8 channels: any line multiple)
+        if (ABS) { // divides the round's bytes, holds a phase + the longest unfinished line (127 bytes)
+            int r = RR * 40 * NCH;
+            while (r % 2 == 0 && (r / 2) % (2 * NCH) == 0 && r / 2 >= PB + 127) r /= 2;
+            return r;
+        }
         int carry = 0, k = 0, pos = 0;
         for (k = 0; k < RR / PR; k++) { pos += PB; int c = pos % LNB; carry = c > carry ? c : carry; }
         int unit = LNB;
@@ -506,10 +525,13 @@ struct K2uCfg {
     // Otherwise RING + 16: the flush reads whole 16-byte pieces with ONE ds_read_b128 each (4 x ds_read_b32 before), and the
     // 2-byte scatter of a half-wave (at most 16 frames, stride 17 or 41 sixteen-byte units) meets at most 2 frames per bank,
     // which a ds_write hides behind its own data transfer (MI355X_MICROARCH.md, LDS: "2-way on ds_write_b32 costs nothing").
+    static constexpr int MIRROR = ABS ? 8 : 0; // bytes of the ring's start written again behind its end (generated rows)
 #ifdef QOA_K2U_GSP_PAD
     static constexpr int GSP = RING + QOA_K2U_GSP_PAD;
 #else
-    static constexpr int GSP = RING + (NCH == 1 ? 4 : 16);
+    // (ABS: RING + 8 = 82 dwords for stereo: the 16 frames of a half-wave's 2-byte scatter fall into 16 different banks, and
+    // three 4-wavefront workgroups still fit a compute unit's LDS only without further padding)
+    static constexpr int GSP = ABS ? RING + MIRROR : RING + (NCH == 1 ? 4 : 16);
 #endif
     static constexpr int IMG_GROUPS = FPW + (LIVE < 64 ? 1 : 0); // + the spare image the mirror lanes scribble into
     // staging units in flight: the slices of unit n + NSLOT are requested at the top of unit n (each slot is one unit's
@@ -525,7 +547,10 @@ struct K2uCfg {
     static constexpr int FLUSH_PRIO = NCH == 8 ? 0 : 3;   // issue priority while a wavefront flushes its lines (see the flush)
 #endif
     // waves per block (multiples of 4 only: other counts load the four SIMDs unevenly -- profiles/r02_k2lab_log.md, run 20)
-    static constexpr int WPB = 4;
+#ifndef QOA_K2U_ABS_WPB // (tools/k2lab: wavefronts per workgroup of the absolute-line variant)
+#define QOA_K2U_ABS_WPB 4
+#endif
+    static constexpr int WPB = ABS ? QOA_K2U_ABS_WPB : 4;
     // vector-memory operations younger than unit n's loads at the top of unit n (steady state): the loads of the NSLOT - 1
     // units requested since, and the stores of the NSLOT units since
     static constexpr int behind(int u) {
@@ -544,10 +569,11 @@ struct K2uCfg {
     static constexpr int SLOT = NLD * 1024;              // one unit's stage: every lane of every load instruction lands 16 bytes
     static constexpr int lines_done(int rows) { return (rows * 40 * NCH) / LNB; } // lines complete after `rows` rows of the round
     // store instructions issued during staging unit u (rows [u*HR, (u+1)*HR) of the round)
+    static constexpr int ABS_SLOTS = (PB + LNB - 1) / LNB; // ABS: store slots per phase (the most lines a phase can complete)
     static constexpr int unit_stores(int u) {
         int n = 0;
         for (int row = u * HR; row < (u + 1) * HR; row++)
-            if ((row + 1) % PR == 0) n += (lines_done(row + 1) - lines_done(row + 1 - PR)) * NLS;
+            if ((row + 1) % PR == 0) n += (ABS ? ABS_SLOTS : lines_done(row + 1) - lines_done(row + 1 - PR)) * NLS;
         return n;
     }
     static_assert(RR % HR == 0 && (HR % PR == 0 || PR % HR == 0) && NLD >= 1 && CB % 16 == 0 && (RR * 40 * NCH) % LNB == 0 &&
@@ -561,15 +587,15 @@ struct K2uCfg {
 #ifndef QOA_K2U_WPB_OVERRIDE
 #define QOA_K2U_WPB_OVERRIDE 0
 #endif
-template <int NCH, int WPB>
+template <int NCH, int WPB, bool ABS = false>
 __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
                                                                      const DecChain *__restrict__ frames, unsigned n_frames,
                                                                      unsigned *__restrict__ mismatches) {
-    typedef K2uCfg<NCH> C;
+    typedef K2uCfg<NCH, ABS> C;
     constexpr int FPW = C::FPW, RR = C::RR, HR = C::HR, PR = C::PR, RING = C::RING, GSP = C::GSP, NLS = C::NLS, NLD = C::NLD,
                   SSP = C::SSP, LPC = C::LPC, CB = C::CB, UNITS = RR / HR, NSLOT = C::NSLOT, SLOT = C::SLOT, LIVE = C::LIVE,
                   LNB = C::LNB, LPL = C::LPL, FPS = C::FPS;
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][C::IMG_GROUPS * GSP + (NCH == 1 ? 12 : 16)];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[WPB][C::IMG_GROUPS * GSP + (ABS ? 8 : NCH == 1 ? 12 : 16)];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[WPB][NSLOT * SLOT];
     __shared__ uint2 s_mags[16];
     // pair table of the generated row (qoa_decode_asm.inc): [sf][code a * 8 + code b] = deq(a) | deq(b) << 16
@@ -655,6 +681,28 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             out_ptr[o] = ((((unsigned long long)ohi) << 32) | olo) + (lane % (unsigned)LPL) * 16u;
         }
     }
+    // ABS: per store role o, this lane's piece q = lane % 8 of the role's frame.  lend = round-relative end of the frame's next
+    // unflushed absolute line (128 (m + 1) - delta), rp = ring offset of this lane's piece of that line; the piece's address is
+    // out_ptr[o] + lend (out_ptr[o] = frame address + 16 q - 128, advanced by the round's bytes per round like the aligned
+    // kernel's).  f_lo[o] = the frame's address: pieces of its first line that lie in front of it are not written.
+    int lend[NLS];
+    unsigned rp[NLS], edge_q[NLS];
+    unsigned long long f_lo[NLS];
+    (void)lend; (void)rp; (void)edge_q; (void)f_lo;
+    if constexpr (ABS) {
+#pragma unroll
+        for (int o = 0; o < NLS; o++) {
+            const unsigned long long fa = out_ptr[o] - (lane % (unsigned)LPL) * 16u; // the role's frame address
+            const unsigned delta = (unsigned)fa & 127u;
+            f_lo[o] = fa;
+            lend[o] = 128 - (int)delta;
+            rp[o] = (unsigned)(RING - (int)delta + 16 * (int)(lane % (unsigned)LPL)) % (unsigned)RING; // piece q of the line that ends at lend
+            // the piece that straddles the frame's start (and, 20480 NCH bytes on, its end) when delta is no multiple of 16:
+            // this lane's if q == delta / 16; 8 = none
+            edge_q[o] = (delta & 15u) ? delta >> 4 : 8u;
+            out_ptr[o] = out_ptr[o] - 128u;
+        }
+    }
     // do all of the wave's frames start on a 128-byte line?  (decides the store policy of the flush, wave-uniform)
 #ifdef QOA_K2U_FORCE_WRITE_BACK // (tools/k2lab)
     const bool lines_aligned = __builtin_amdgcn_ballot_w64(((unsigned long long)(out + fr.out_off)) != 0ull) == 0ull;
@@ -694,7 +742,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     // n + NSLOT may overwrite the slot
     auto unit_top = [&](auto uc, unsigned n) {
         constexpr int u = decltype(uc)::value;
-        if (n < (unsigned)NSLOT || n + NSLOT > kUnits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (ABS: the frame's first 8 bytes may go out in unit 0 -- one store more than the static count -- so unit 1 drains too)
+        if (n < (unsigned)NSLOT + (ABS ? 1u : 0u) || n + NSLOT > kUnits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(C::behind(u)) : "memory");
         const unsigned slot_off = NSLOT == 1 ? 0u : (n % NSLOT) * SLOT;
 #pragma unroll
@@ -711,13 +760,15 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             if constexpr (row % HR == 0)
                 unit_top(std::integral_constant<int, row / HR>{}, round * UNITS + row / HR);
             {
-                static_assert(RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 3 ? QOA_DEC_ASM_RING_3
+                static_assert(ABS || RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 3 ? QOA_DEC_ASM_RING_3
                                        : NCH == 4 ? QOA_DEC_ASM_RING_4 : NCH == 5 ? QOA_DEC_ASM_RING_5 : NCH == 6 ? QOA_DEC_ASM_RING_6
                                        : NCH == 7 ? QOA_DEC_ASM_RING_7 : QOA_DEC_ASM_RING_8) &&
                                   RR == (NCH == 1 ? QOA_DEC_ASM_ROWS_1 : NCH == 2 ? QOA_DEC_ASM_ROWS_2 : NCH == 3 ? QOA_DEC_ASM_ROWS_3
                                          : NCH == 4 ? QOA_DEC_ASM_ROWS_4 : NCH == 5 ? QOA_DEC_ASM_ROWS_5 : NCH == 6 ? QOA_DEC_ASM_ROWS_6
                                          : NCH == 7 ? QOA_DEC_ASM_ROWS_7 : QOA_DEC_ASM_ROWS_8),
                               "generated image offsets");
+                static_assert(!ABS || (RING == QOA_DEC_ASM_ABS_RING_2 && C::MIRROR == QOA_DEC_ASM_ABS_MIRROR_2 && RR == QOA_DEC_ASM_ROWS_2),
+                              "generated image offsets (absolute-line rows)");
                 const uint2 raw = unit_raw[row % HR];
                 unsigned force = 0, flag = 0;
                 bool need_slow = false;
@@ -735,7 +786,20 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                      : [rx] "v"(raw.x), [ry] "v"(raw.y), [tab] "s"(tab_lds), [grow] "s"(grow_lds), [img] "v"(img_lds),  \
                        [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [force] "s"(force)                            \
                      : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS);
-                    QOA_DEC_ROW_CASES // (generated: one case per (channel count, row of the round))
+#define QOA_DEC_ROW_CASE_ABS(N, R)                                                                                     \
+    if constexpr (NCH == N && row == R)                                                                                \
+        asm volatile(QOA_DEC_ROW_TEXT_A##N##_##R                                                                       \
+                     : [w01] "+v"(pk.w01), [w23] "+v"(pk.w23), [pa] "+v"(pk.pa), [pm] "+v"(pk.pm), [pb] "+v"(pk.pb),   \
+                       [sa] "+v"(pk.sa), [sm] "+v"(pk.sm), [sb] "+v"(pk.sb), [slack] "+v"(slack), [flag] "=s"(flag)    \
+                     : [rx] "v"(raw.x), [ry] "v"(raw.y), [tab] "s"(tab_lds), [grow] "s"(grow_lds), [img] "v"(img_lds),  \
+                       [bsw] "s"(0x00010203u), [one2] "s"(0x00010001u), [force] "s"(force)                            \
+                     : "memory", "vcc", "scc", QOA_DEC_ROW_CLOBBERS);
+                    if constexpr (ABS) {
+                        QOA_DEC_ROW_CASES_ABS // (generated: the rows of the absolute-line variant)
+                    } else {
+                        QOA_DEC_ROW_CASES // (generated: one case per (channel count, row of the round))
+                    }
+#undef QOA_DEC_ROW_CASE_ABS
 #undef QOA_DEC_ROW_CASE
                     if (flag == 0) break;
                     // the cheap guard tripped (nothing was executed): exact test on the current weights
@@ -753,14 +817,78 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 #pragma unroll 1
                     for (int i = 0; i < 20; i++) {
                         int rec = decode_step(l, s0, s1, s2, s3, (unsigned)(slice >> (57 - 3 * i)) & 7u, dq.x, dq.y);
-                        *(int16_t *)(img + my_img + (unsigned)((row * 20 + i) * NCH * 2) % (unsigned)RING) = (int16_t)rec;
+                        const unsigned ro = (unsigned)((row * 20 + i) * NCH * 2) % (unsigned)RING;
+                        *(int16_t *)(img + my_img + ro) = (int16_t)rec;
+                        if (ABS && ro < (unsigned)C::MIRROR) *(int16_t *)(img + my_img + ro + RING) = (int16_t)rec; // (as the generated rows)
                     }
                     packed = fits_i16(l.w0) && fits_i16(l.w1) && fits_i16(l.w2) && fits_i16(l.w3);
                     dec_pack(l, pk);
                     slack = packed ? dec_slack(pk) : -0x40000000;
                 }
             }
-            if constexpr ((row + 1) % PR == 0) {
+            if constexpr (ABS && (row + 1) % PR == 0) {
+                // ---- absolute-line flush: the lines of every frame that are complete now, as whole cache lines ----
+                constexpr int P = (row + 1) * 40 * NCH; // bytes of the round written so far
+                typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+                typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(4)));
+                asm volatile("" ::: "memory"); // the image was written as int16: keep the reads below behind those stores
+                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO);
+                u4_unaligned vv[C::ABS_SLOTS][NLS];
+                unsigned long long ga[C::ABS_SLOTS][NLS], ok_mask[C::ABS_SLOTS][NLS];
+                const unsigned frame_img = (lane / (unsigned)LPL) * GSP;
+                static_for<0, C::ABS_SLOTS>([&](auto sc) {
+                    constexpr int sl = decltype(sc)::value;
+                    static_for<0, NLS>([&](auto oc) {
+                        constexpr int o = decltype(oc)::value;
+                        const bool valid = lend[o] <= P; // the frame's next line is complete
+                        vv[sl][o] = *(const u4_unaligned *)(img + frame_img + o * FPS * GSP + rp[o]);
+                        ga[sl][o] = out_ptr[o] + (unsigned long long)(long long)lend[o];
+                        // (a piece of the frame's first line that lies in front of the frame, or straddles its start, is not written)
+                        ok_mask[sl][o] = __builtin_amdgcn_ballot_w64(valid && ga[sl][o] >= f_lo[o]);
+                        const unsigned rn = rp[o] + (unsigned)LNB;
+                        rp[o] = valid ? min(rn, rn - (unsigned)RING) : rp[o]; // (+ 128) mod RING
+                        lend[o] += valid ? LNB : 0;
+                    });
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("; K2u absolute-line flush, streamed stores" ::: "memory");
+                static_for<0, C::ABS_SLOTS>([&](auto sc) {
+                    constexpr int sl = decltype(sc)::value;
+                    static_for<0, NLS>([&](auto oc) {
+                        constexpr int o = decltype(oc)::value;
+                        // always issued (the static vmcnt bookkeeping of the slice loads counts it), lanes without a complete line off
+                        unsigned long long keep;
+                        const unsigned long long a_ = ga[sl][o], m_ = ok_mask[sl][o]; // (copies: an asm operand alone does not
+                        const u4_unaligned v_ = vv[sl][o];                            // capture the enclosing lambda's arrays)
+                        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_store_dwordx4 %1, %2, off nt\n\t"
+                                     "s_mov_b64 exec, %0"
+                                     : "=&s"(keep) : "v"(a_), "v"(v_), "s"(m_) : "memory", "scc");
+                    });
+                });
+                if constexpr (row + 1 == PR) {
+                    // the frame's first bytes where its address is no multiple of 16: the 8 bytes of the straddling piece that
+                    // belong to it (ring [0, 8)), once per frame -- one store more in unit 0 than the static count (unit_top)
+                    if (round == 0) {
+                        static_for<0, NLS>([&](auto oc) {
+                            constexpr int o = decltype(oc)::value;
+                            const u2_unaligned h = *(const u2_unaligned *)(img + frame_img + o * FPS * GSP);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64((lane % (unsigned)LPL) == edge_q[o]);
+                            unsigned long long keep;
+                            const unsigned long long fa_ = f_lo[o];
+                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\t"
+                                         "global_store_dwordx2 %1, %2, off\n\ts_mov_b64 exec, %0"
+                                         : "=&s"(keep) : "v"(fa_), "v"(h), "s"(m) : "memory", "scc");
+                        });
+                    }
+                }
+                if constexpr (row + 1 == RR) {
+#pragma unroll
+                    for (int o = 0; o < NLS; o++) lend[o] -= RR * 40 * NCH; // the next round counts from its own start
+                }
+                asm volatile("; end of the absolute-line burst" ::: "memory");
+                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+            }
+            if constexpr (!ABS && (row + 1) % PR == 0) {
                 // flush the lines this phase completed
                 constexpr int l0 = C::lines_done(row + 1 - PR), l1 = C::lines_done(row + 1);
                 typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
@@ -845,6 +973,28 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 #pragma unroll
         for (int o = 0; o < NLS; o++) out_ptr[o] += RR * 40 * NCH; // the round's PCM per frame (whole lines: 640 B, or 1920 .. 4480 B)
     }
+    if constexpr (ABS) {
+        // ---- the frame's last line: what is left in the ring (delta bytes).  lend counts from the frame's END now: this lane's
+        // piece starts at lend - 128 + 16 q <= 0; whole pieces in front of the end go out as one masked line, the piece that
+        // straddles the end (delta no multiple of 16) gives its first 8 bytes ----
+        typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+        typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(4)));
+        asm volatile("" ::: "memory");
+        const unsigned frame_img = (lane / (unsigned)LPL) * GSP;
+        static_for<0, NLS>([&](auto oc) {
+            constexpr int o = decltype(oc)::value;
+            const int start = lend[o] - LNB + 16 * (int)(lane % (unsigned)LPL);
+            const u4_unaligned v = *(const u4_unaligned *)(img + frame_img + o * FPS * GSP + rp[o]);
+            const unsigned long long a = out_ptr[o] + (unsigned long long)(long long)lend[o];
+            const unsigned long long m16 = __builtin_amdgcn_ballot_w64(start + 16 <= 0);
+            const unsigned long long m8 = __builtin_amdgcn_ballot_w64(start == -8);
+            const u2_unaligned v8 = u2_unaligned{v[0], v[1]};
+            unsigned long long keep;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_store_dwordx4 %1, %2, off nt\n\t"
+                         "s_mov_b64 exec, %0\n\ts_and_b64 exec, exec, %5\n\tglobal_store_dwordx2 %1, %4, off\n\ts_mov_b64 exec, %0"
+                         : "=&s"(keep) : "v"(a), "v"(v), "s"(m16), "v"(v8), "s"(m8) : "memory", "scc");
+        });
+    }
 }
 
 
@@ -879,11 +1029,11 @@ static hipError_t launch_decode_frames_r(int nch, const uint8_t *in, int16_t *ou
     return hipGetLastError();
 }
 
-template <int NCH>
+template <int NCH, bool ABS = false>
 static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
                                           unsigned *mismatches, hipStream_t stream) {
     constexpr unsigned FPW = 64 / NCH;
-    constexpr unsigned W = QOA_K2U_WPB_OVERRIDE ? QOA_K2U_WPB_OVERRIDE : K2uCfg<NCH>::WPB;
+    constexpr unsigned W = QOA_K2U_WPB_OVERRIDE ? QOA_K2U_WPB_OVERRIDE : K2uCfg<NCH, ABS>::WPB;
     const unsigned waves = (n_frames + FPW - 1) / FPW; // (the last wave's spare frame slots repeat its last frame)
     // ONE launch: the last block may be short of waves (they leave behind the table barrier).  A second, small launch for a
     // remainder runs after the first on the stream, alone on the chip, for as long as a full wave takes (+0.25 ms measured).
@@ -895,10 +1045,10 @@ static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const
     const unsigned dyn_lds = 0u;
 #endif
     if (waves >= 256u * W)
-        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, W>), dim3((waves + W - 1) / W), dim3(64 * W), dyn_lds, stream, in, out,
+        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, W, ABS>), dim3((waves + W - 1) / W), dim3(64 * W), dyn_lds, stream, in, out,
                            frames, n_frames, mismatches);
     else
-        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, 1>), dim3(waves), dim3(64), 0, stream, in, out, frames, n_frames,
+        hipLaunchKernelGGL((qoa_decode_uniform_kernel<NCH, 1, ABS>), dim3(waves), dim3(64), 0, stream, in, out, frames, n_frames,
                            mismatches);
     return hipGetLastError();
 }
@@ -915,6 +1065,15 @@ hipError_t launch_decode_uniform(int nch, const uint8_t *in, int16_t *out, const
     case 6: return launch_decode_uniform_n<6>(in, out, frames, n_frames, mismatches, stream);
     case 7: return launch_decode_uniform_n<7>(in, out, frames, n_frames, mismatches, stream);
     case 8: return launch_decode_uniform_n<8>(in, out, frames, n_frames, mismatches, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_decode_uniform_abs(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
+                                     unsigned *mismatches, hipStream_t stream) {
+    if (n_frames == 0) return hipSuccess;
+    switch (nch) {
+    case 2: return launch_decode_uniform_n<2, true>(in, out, frames, n_frames, mismatches, stream);
     default: return hipErrorInvalidValue;
     }
 }

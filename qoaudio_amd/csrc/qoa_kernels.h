@@ -60,6 +60,12 @@ hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *d_in,
 constexpr unsigned decode_uniform_group(int nch) { return nch >= 1 && nch <= 8 ? 64u / (unsigned)nch : 0u; }
 hipError_t launch_decode_uniform(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames, unsigned n_frames,
                                  unsigned *d_mismatches, hipStream_t stream);
+// K2u's absolute-line variant (round 5): uniform frames whose PCM address is off the 128-byte grid but a multiple of 8 -- the
+// flush works on the frame's absolute cache lines (whole-line streamed stores; the frame's first and last line partial).
+// Also correct, just not needed, for frames on the grid.  decode_uniform_abs_supported(nch): the channel counts it is built for.
+constexpr bool decode_uniform_abs_supported(int nch) { return nch == 2; }
+hipError_t launch_decode_uniform_abs(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames, unsigned n_frames,
+                                     unsigned *d_mismatches, hipStream_t stream);
 
 // test hook: one slice, 16 candidates (device pointers; tot/fst/slice: 16 x u64, end_state: 16 x 8 x i32)
 hipError_t launch_debug_slice(const int32_t *d_state, const int32_t *d_samples, int len, int generic,

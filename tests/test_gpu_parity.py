@@ -1198,3 +1198,69 @@ def test_wave_stats_tell_what_a_batch_cost(gpu, oracle):
         batch.EncodePlan(clips, batch.PLAN_WAVE_STATS | batch.PLAN_CPW_2)
     with pytest.raises(gpu.EncodeError):
         batch.EncodePlan(clips).wave_stats()
+
+
+@pytest.mark.parametrize("n_streams", [3, 70])
+def test_k2u_absolute_line_flush_at_every_offset(gpu, oracle, n_streams):
+    """K2u's absolute-line variant (round 5; stereo): full frames whose PCM is off the 128-byte grid but on the 8-byte grid are
+    flushed as whole ABSOLUTE cache lines -- the frame's first and last line partial, 8 single bytes at either end where the
+    address is no multiple of 16.  Streams of 2 .. 5 full frames (music, hostile headers + all-ones slices that take the 32-bit
+    rows, random garbage) at PCM offsets that run through EVERY multiple of 4 bytes modulo 128 (offsets that are 4 mod 8 stay on
+    K2u's write-back path, offsets 0 mod 128 on its streamed path: all three launches in one plan), packed so tightly that a
+    frame's first / last line is shared with its neighbour stream's last / first; the output buffer is pre-filled with a
+    pattern and every byte outside the streams must still hold it (no masked piece may leak).  Both block shapes (n_streams = 3:
+    one wavefront per workgroup; 70: four, several workgroups).  Sample for sample against the oracle's decoder
+    (src/lib.rs:291-330)."""
+    from qoaudio_amd import batch
+    channels = 2
+    r = np.random.default_rng(77 + n_streams)
+    fs = 8 + 16 * channels + 8 * 256 * channels
+    streams, n_frames = [], []
+    music = oracle.encode_all(rng_pcm(31, 5 * 5120 * channels), channels, 44100, 5 * 5120)
+    for k in range(n_streams):
+        nf = 2 + k % 4
+        if k % 3 == 0:
+            st = oracle.encode_all(rng_pcm(100 + k, nf * 5120 * channels), channels, 44100, nf * 5120)
+        elif k % 3 == 1:
+            st = bytearray(_crafted_stream(r, [(channels, 44100, 5120, 256)] * nf, samples_field=nf * 5120))
+            for f in range(nf):
+                base = 8 + f * fs
+                st[base + 8:base + 8 + 16 * channels] = bytes([0x80, 0x00, 0x7f, 0xff] * (4 * channels))
+                body = base + 8 + 16 * channels
+                st[body:body + 30 * 8 * channels] = b"\xff" * (30 * 8 * channels)
+            st = bytes(st)
+        else:
+            st = _crafted_stream(r, [(channels, 8000, 5120, 256)] * nf, samples_field=nf * 5120)
+        streams.append(st)
+        n_frames.append(nf)
+    offs_in, offs_out, a, b = [], [], 0, 64
+    for k, (st, nf) in enumerate(zip(streams, n_frames)):
+        delta = (4 * (k * 7 + 1)) % 128 if k else 0               # every multiple of 4 modulo 128 over 32 streams
+        b = b + (delta // 2 - b) % 64                               # int16 index with (2 b) % 128 == delta, no gap of a line
+        offs_in.append(a)
+        offs_out.append(b)
+        a += (len(st) + 7) // 8 * 8
+        b += nf * 5120 * channels
+    total = b + 64
+    plan = batch.DecodePlan.from_streams(streams, offs_in, offs_out)
+    assert plan.status == [0] * n_streams
+    buf = np.zeros(a, np.uint8)
+    for st, o in zip(streams, offs_in):
+        buf[o:o + len(st)] = np.frombuffer(st, np.uint8)
+    pattern = ((np.arange(total) * 7 + 3) % 251 - 125).astype(np.int16)
+    d_in = torch.from_numpy(buf).cuda()
+    for rep in range(2):
+        out = torch.from_numpy(pattern.copy()).cuda()
+        assert out.data_ptr() % 128 == 0
+        plan.run(d_in, out)
+        torch.cuda.synchronize()
+        host = out.cpu().numpy()
+        covered = np.zeros(total, bool)
+        for st, o, n in zip(streams, offs_out, plan.samples_out):
+            _, _, want = oracle.decode_all(st)
+            assert n == len(want)
+            bad = np.nonzero(host[o:o + n] != want)[0]
+            assert bad.size == 0, (o, (2 * o) % 128, bad[:8], n)
+            covered[o:o + n] = True
+        assert np.array_equal(host[~covered], pattern[~covered])
+    assert plan.mismatches() == 0

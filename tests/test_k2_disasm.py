@@ -164,8 +164,8 @@ def test_k2u_flush_stores_issue_at_raised_priority(kernels):
     for name, ins in kernels.items():
         if "qoa_decode_uniform_kernel" not in name:
             continue
-        m = re.search(r"qoa_decode_uniform_kernelILi(\d+)ELi(\d+)E", name)
-        nch = int(m.group(1))
+        m = re.search(r"qoa_decode_uniform_kernelILi(\d+)ELi(\d+)ELb([01])E", name)
+        nch, absolute = int(m.group(1)), m.group(3) == "1"
         prio, raised_stores, plain_stores = 0, 0, 0
         for i in ins:
             op = i.split()[0]
@@ -182,6 +182,17 @@ def test_k2u_flush_stores_issue_at_raised_priority(kernels):
         # two bursts into one and dropped the nt hint with it)
         nt = sum(1 for i in ins if i.split()[0] == "global_store_dwordx4" and " nt" in i)
         wb = sum(1 for i in ins if i.split()[0] == "global_store_dwordx4" and " nt" not in i)
+        if absolute:
+            # the absolute-line variant (round 5): whole absolute lines only, every line store streamed and under a lane mask
+            # (always issued: the static vmcnt count of the slice loads includes it) -- all but the frame's last line, which goes
+            # out behind the loop, inside the raised-priority window
+            assert nt > 0 and wb == 0 and raised_stores == 8 * plain_stores and raised_stores + plain_stores == nt, (name, nt, wb, raised_stores, plain_stores)  # (stereo: 4 phases x 2 slots per round; the last line once)
+            for k, i in enumerate(ins):
+                if i.split()[0] in ("global_store_dwordx4", "global_store_dwordx2"):
+                    assert re.match(r"s_and_b64 exec, exec, s\[\d+:\d+\]", ins[k - 1]), (name, ins[k - 2:k + 2])
+                    assert re.match(r"s_mov_b64 exec, s\[\d+:\d+\]", ins[k + 1]), (name, ins[k - 2:k + 2])
+            seen += 1
+            continue
         assert nt > 0 and wb > 0 and (nch not in (1, 2, 4, 8) or nt == wb), (name, nt, wb)
         if nch == 8:
             assert raised_stores == 0, name
@@ -201,7 +212,7 @@ def test_k2u_masked_store_restores_exec(kernels):
     seen = 0
     scc_readers = ("s_cselect", "s_cbranch_scc", "s_addc_u32", "s_subb_u32", "s_cmov")
     for name, ins in kernels.items():
-        m = re.search(r"qoa_decode_uniform_kernelILi(\d+)ELi(\d+)E", name)
+        m = re.search(r"qoa_decode_uniform_kernelILi(\d+)ELi(\d+)ELb0E", name)
         if not m or int(m.group(1)) not in (3, 5, 6, 7):
             continue
         n_masked = 0

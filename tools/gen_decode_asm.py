@@ -73,7 +73,7 @@ def deltas(j0, j1):
     return [f"v_pk_ashrrev_i16 v{D0 + j}, 4, v{E0 + j} op_sel_hi:[0,1]" for j in range(j0, j1)]
 
 
-def step(i, nch, row, ring_bytes):
+def step(i, nch, row, ring_bytes, mirror=0):
     R, S = ring("P"), ring("S")
     A, B, Bn = R[(i + 2) % 4], R[i % 4], R[(i + 1) % 4]
     SA, SB = S[(i + 2) % 4], S[i % 4]
@@ -99,10 +99,12 @@ def step(i, nch, row, ring_bytes):
     else:
         off = ((row * 20 + i) * nch * 2) % ring_bytes
         L.append(f"ds_write_b16_d16_hi %[img], {Bn} offset:{off}")   # the new sample is the pair's high half
+        if off < mirror:   # (absolute-line rows: the ring's first bytes again behind its end, see GEOMETRY_ABS)
+            L.append(f"ds_write_b16_d16_hi %[img], {Bn} offset:{off + ring_bytes}")
     return L
 
 
-def row_text(nch, row, ring_bytes):
+def row_text(nch, row, ring_bytes, mirror=0):
     L = [
         f"v_perm_b32 v{HI}, %[rx], %[rx], %[bsw]",
         f"v_perm_b32 v{LO}, %[ry], %[ry], %[bsw]",
@@ -128,7 +130,7 @@ def row_text(nch, row, ring_bytes):
         if i == 8:
             # before sample 10: everything but the youngest image writes; the table reads are all older than those
             L += ["s_waitcnt lgkmcnt(%d)" % (4 if nch == 1 else 8)] + deltas(5, 10)
-        L += step(i, nch, row, ring_bytes)
+        L += step(i, nch, row, ring_bytes, mirror)
     L += [
         "s_mov_b32 %[flag], 0",
         "s_branch Lqoa_end_%=",
@@ -189,6 +191,15 @@ GEOMETRY = {1: (16, int(os.environ.get("QOA_DEC_RING1", "256"))), 2: (8, int(os.
             3: (16, 384), 5: (16, 640), 6: (8, 768), 7: (16, 896)}
 
 
+# Rows of the ABSOLUTE-LINE variant of K2u (round 5: frames whose PCM is off the 128-byte grid): (rows per round, ring bytes,
+# mirror bytes).  There the flush reads 16-byte pieces that are aligned to the frame's absolute cache lines, i.e. at ring
+# offsets congruent to -(address mod 128): a piece may start 8 bytes before the ring's end, so the ring's first `mirror` bytes
+# are written a second time behind its end (the sample's lane issues a second ds_write: 2 of 80 per ring revolution) and every
+# piece is 16 contiguous bytes.  The ring divides the round's bytes (640), so that the bytes a round leaves behind for the next
+# round's first line sit where that line's pieces look for them.  Must agree with K2uCfg<NCH, true> in qoa_decode.hip.
+GEOMETRY_ABS = {2: (8, 320, 8)}
+
+
 def render():
     out = ["// GENERATED by tools/gen_decode_asm.py -- do not edit.",
            "// QOA_DEC_ROW_TEXT_<channels>_<row of the round>: one slice row of K2u (20 samples of every chain of the wave) on",
@@ -196,6 +207,11 @@ def render():
            f"#define QOA_DEC_ROW_CLOBBERS " + ", ".join(f'"v{r}"' for r in CLOBBERS),
            ] + ["#define QOA_DEC_ASM_RING_%d %d" % (n, GEOMETRY[n][1]) for n in sorted(GEOMETRY)] + [
                "#define QOA_DEC_ASM_ROWS_%d %d" % (n, GEOMETRY[n][0]) for n in sorted(GEOMETRY)] + [
+               "#define QOA_DEC_ASM_ABS_RING_%d %d" % (n, GEOMETRY_ABS[n][1]) for n in sorted(GEOMETRY_ABS)] + [
+               "#define QOA_DEC_ASM_ABS_MIRROR_%d %d" % (n, GEOMETRY_ABS[n][2]) for n in sorted(GEOMETRY_ABS)] + [
+               "// ... and over the rows of the absolute-line variant: QOA_DEC_ROW_CASE_ABS(N, R) -> QOA_DEC_ROW_TEXT_A<N>_<R>",
+               "#define QOA_DEC_ROW_CASES_ABS " + " ".join(f"QOA_DEC_ROW_CASE_ABS({n}, {r})" for n in sorted(GEOMETRY_ABS)
+                                                            for r in range(GEOMETRY_ABS[n][0])),
                "// the kernel's dispatch over (channel count, row of the round): expands QOA_DEC_ROW_CASE(N, R) for every text below",
                "#define QOA_DEC_ROW_CASES " + " ".join(f"QOA_DEC_ROW_CASE({n}, {r})" for n in sorted(GEOMETRY) for r in range(GEOMETRY[n][0])),
                ""]
@@ -207,6 +223,12 @@ def render():
             check_hazards(t)
             n_lines = len(t)
             out.append(emit(f"QOA_DEC_ROW_TEXT_{nch}_{row}", t))
+    for nch, (rows, ring_bytes, mirror) in sorted(GEOMETRY_ABS.items()):
+        assert nch > 1 and (rows * 40 * nch) % ring_bytes == 0 and ring_bytes % (2 * nch) == 0 and mirror % (2 * nch) == 0
+        for row in range(rows):
+            t = row_text(nch, row, ring_bytes, mirror)
+            check_hazards(t)
+            out.append(emit(f"QOA_DEC_ROW_TEXT_A{nch}_{row}", t))
     return "\n".join(out), n_lines
 
 
