@@ -201,7 +201,7 @@ def other_configs(q, batch, synth, dev, stream, pcm, rate, n_clips, frames):
 
 def decode_over_placements(q, batch, dplan, enc, pcm_like, stream, pairs=4, warm=8, reps=10):
     """The decode launch on `pairs` separately allocated (input, output) buffer pairs: K2u's time depends on where its buffers
-    lie (a stable property of the pair of allocations), so one pair reports the allocator's luck; the
+    lie (a stable property of the pair of allocations, LABLOG.md K2u item 6), so one pair reports the allocator's luck; the
     figure to quote is the median over pairs.  Returns (per-pair mean kernel ms, the last pair's output)."""
     per_pair, back = [], None
     keep = []  # (all pairs stay allocated while the others are timed: they must be distinct placements)
@@ -234,7 +234,7 @@ def decode_record(dplan, per_pair, kernel, traffic=None, traffic_note=None):
                         "frac_worst_placement": d_bytes / (max(per_pair) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "kernel": kernel, "algorithmic_bytes_per_launch": d_bytes},
            "note": f"median over {len(per_pair)} separately allocated (input, output) buffer pairs, each the mean of back-to-back "
-                   "launches behind a warm-up: the same launch differs by several per cent between allocations (DESIGN.md K2u item 6)"}
+                   "launches behind a warm-up: the same launch differs by several per cent between allocations (LABLOG.md K2u item 6)"}
     if traffic_note:
         rec["roofline"]["traffic_note"] = traffic_note
     return rec
@@ -770,7 +770,7 @@ def main():
         del back
 
     if rank == 0 and world == 1 and not args.no_extras and args.frames % 8 == 0:
-        # K1 outside the headline shape (records for DESIGN.md, not part of `value`): the same 2048 chains at 2 chains per
+        # K1 outside the headline shape (lab records, not part of `value`): the same 2048 chains at 2 chains per
         # wavefront (1024 wavefronts, one per SIMD), and a batch with a full wavefront for every SIMD several times over
         # (8192 clips x 32 frames: the same 5.4 GB of PCM, 16384 chains = 4096 wavefronts, 4 per SIMD)
         extras = {}

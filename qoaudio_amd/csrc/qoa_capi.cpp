@@ -1319,7 +1319,7 @@ extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count
 // is cut along time exactly like the encode pipeline but without any carried state: frames [j*F, (j+1)*F) of all clips
 // are copied in (their bytes are contiguous per clip), decoded by K2 / K2u, and their PCM copied out, the three stages of
 // neighbouring slices overlapping on three streams.  The copy out moves 2 bytes per sample over PCIe: this pipeline is
-// bound by that transfer by construction (DESIGN.md section 5 has the measured rates), not by the kernel.
+// bound by that transfer by construction (LABLOG.md section 5 and bench.py's e2e record have the measured rates), not by the kernel.
 // Layout trusted like qoa_decode_plan_from_clips; every frame header is verified on the device.
 // ------------------------------------------------------------------------------------------------
 struct DecTablesHolder {

@@ -159,7 +159,7 @@ def test_decode_kernels_do_not_spill(kernels):
 
 def test_k2u_flush_stores_issue_at_raised_priority(kernels):
     """K2u's line stores (1 / 2 / 4 channels) go out with the wavefront's issue priority raised (s_setprio 3 ... s_setprio 0:
-    DESIGN.md K2u item 6) -- hipcc must not have moved the stores out of that window or dropped the pair."""
+    LABLOG.md K2u item 6) -- hipcc must not have moved the stores out of that window or dropped the pair."""
     seen = 0
     for name, ins in kernels.items():
         if "qoa_decode_uniform_kernel" not in name:

@@ -18,9 +18,16 @@ def f(x, n=1):
 
 
 def load(path):
-    for line in reversed(open(path).read().strip().splitlines()):
-        if line.startswith("{"):
-            return json.loads(line)
+    """The FULL record: bench.py (round 5) prints it first, as {"bench_extras": {...}}, and the contract's <= 6 KB line last;
+    --extras-file writes the full record alone; older files hold one line with everything."""
+    text = open(path).read().strip()
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    for line in lines:
+        d = json.loads(line)
+        if "bench_extras" in d:
+            return d["bench_extras"]
+    if lines:
+        return json.loads(lines[-1])
     raise SystemExit(f"no JSON line in {path}")
 
 
@@ -38,14 +45,20 @@ def baseline_block(d, src):
     if "value" in cpu:
         enc += (f".  CPU (oracle ref_style, same clips, same run): 1 thread {f(cpu['value'] / 1e6, 1)} M samples/s -> "
                 f"**{f(d['speedup_vs_cpu_1_thread'], 0)}x**")
-        if "all_cores" in cpu:
-            enc += f"; {cpu['all_cores']['cores']} threads {f(cpu['all_cores']['value'] / 1e6, 0)} M -> {f(d['value'] / cpu['all_cores']['value'], 0)}x"
+        if "all_cores_value" in cpu:
+            enc += (f"; all {cpu['all_cores_workers']} usable CPUs (of {cpu.get('cores_visible')} visible; cgroup quota {cpu.get('cgroup_cpu_quota')}) "
+                    f"{f(cpu['all_cores_value'] / 1e6, 0)} M -> {f(d['value'] / cpu['all_cores_value'], 0)}x (scaling efficiency "
+                    f"{f(cpu['scaling_efficiency'], 2)})")
     rows.append(("3 (headline): " + d["config"]["workload"], enc + f"; bit-exact vs oracle: {d.get('bit_exact_vs_oracle')}"))
     if dec:
         rr = dec["roofline"]
-        rows.append(("3, decode half of the round trip", f"**{f(dec['kernel_ms_avg'], 3)} ms** median over {len(dec['kernel_ms_per_placement'])} "
-                     f"buffer placements ({', '.join(f(v, 3) for v in dec['kernel_ms_per_placement'])}) = {f(dec['value'] / 1e12, 2)} T samples/s = "
-                     f"**{f(rr['frac'], 3)} of the HBM peak** (best placement {f(rr['frac_best_placement'], 3)}, worst {f(rr['frac_worst_placement'], 3)})"))
+        row = (f"**{f(dec['kernel_ms_avg'], 3)} ms** median over {len(dec['kernel_ms_per_placement'])} "
+               f"buffer placements ({', '.join(f(v, 3) for v in dec['kernel_ms_per_placement'])}) = {f(dec['value'] / 1e12, 2)} T samples/s = "
+               f"**{f(rr['frac'], 3)} of the HBM peak** (best placement {f(rr['frac_best_placement'], 3)}, worst {f(rr['frac_worst_placement'], 3)})")
+        if "decode_value" in cpu:
+            row += (f".  CPU (oracle decode_all, the same streams, 1 thread): {f(cpu['decode_value'] / 1e6, 0)} M samples/s -> "
+                    f"{f(dec['value'] / cpu['decode_value'], 0)}x; PCM equal: {cpu.get('gpu_pcm_equals_cpu_pcm')}")
+        rows.append(("3, decode half of the round trip", row))
     k2 = d.get("k2_extras", {})
     if "mono" in k2:
         m = k2["mono"]
@@ -66,14 +79,21 @@ def baseline_block(d, src):
     if "full_chip" in x:
         c = x["full_chip"]
         rows.append(("K1 with every SIMD busy: " + c["workload"], f"{f(c['kernel_ms_avg'], 2)} ms = {f(c['samples_per_s'] / 1e9, 1)} G samples/s"))
-    out = [f"Generated by `tools/gen_results_md.py` from `{src}` (one `python bench.py` line on one MI355X; host "
-           f"{cpu.get('all_cores', {}).get('cores', '?')} hardware threads).", "",
+    e2e = d.get("e2e", {})
+    if "encode" in e2e:
+        rows.append(("3 end to end: " + e2e["workload"],
+                     f"encode {f(e2e['encode']['wall_ms'], 1)} ms = **{f(e2e['encode']['samples_per_s'] / 1e9, 1)} G samples/s** "
+                     f"({f(e2e['encode']['host_to_device_GBps'], 1)} GB/s of PCM over PCIe: the bound), decode {f(e2e['decode']['wall_ms'], 1)} ms = "
+                     f"{f(e2e['decode']['samples_per_s'] / 1e9, 1)} G samples/s; bytes / PCM equal to the device-resident path: "
+                     f"{e2e['encode']['bytes_equal_device_path']} / {e2e['decode']['pcm_equal_device_path']} (PCIe-inclusive: never `value`)"))
+    out = [f"Generated by `tools/gen_results_md.py` from `{src}` (one `python bench.py` run on one MI355X; host: "
+           f"{cpu.get('cores_visible', '?')} hardware threads visible, {cpu.get('cores_usable', '?')} usable by the bench process).", "",
            "| Config | GPU result |", "|---|---|"]
     out += [f"| {a} | {b} |" for a, b in rows]
     sc = x.get("signal_classes", {})
     if sc:
         out += ["", f"Signal classes ({sc.get('workload')}; the batch waits for its slowest wavefront):", "",
-                "| input | kernel ms | ns per slice | vs music | bit-exact | which forms it reached (counters of a counting plan) |", "|---|---|---|---|---|---|"]
+                "| input | kernel ms | ns per slice | vs music | bit-exact | which forms it reached (counters of a counting plan) | per wavefront: cycles per slice p50 / max (bound), the slowest one's form mix |", "|---|---|---|---|---|---|---|"]
         for k in ("music", "silence", "fixture", "white", "loud"):
             if k not in sc:
                 continue
@@ -82,7 +102,10 @@ def baseline_block(d, src):
                      f"{cn.get('penalty_form_declines', 0)}, packed declines {cn['declined_slices']}, wave-slices on the wide form "
                      f"{cn.get('wavefront_slices_on_wide_form', 0)} / on the 32-bit step {cn.get('wavefront_slices_on_32bit_step', 0)} "
                      f"of {cn['slices_total'] // 4}")
-            out.append(f"| {k} | {f(c['kernel_ms'], 2)} | {f(c['ns_per_slice'], 0)} | {f(c.get('vs_music', 1.0), 3)} | {c['bit_exact_vs_oracle']} | {forms} |")
+            pw = c.get("per_wavefront")
+            pws = (f"{f(pw['cycles_per_slice_p50'], 0)} / {f(pw['cycles_per_slice_max'], 0)} ({f(pw['bound_cycles_per_slice'], 0)}); "
+                   + ", ".join(f"{kk} {vv}" for kk, vv in pw["slowest_wavefront_form_mix"].items() if kk != "blocks")) if pw else ""
+            out.append(f"| {k} | {f(c['kernel_ms'], 2)} | {f(c['ns_per_slice'], 0)} | {f(c.get('vs_music', 1.0), 3)} | {c['bit_exact_vs_oracle']} | {forms} | {pws} |")
     sl = x.get("small_launch", {})
     if sl:
         out += ["", "Small launches (" + sl.get("workload", "") + "): " + ", ".join(
@@ -99,8 +122,8 @@ def readme_block(d, src):
          f"256 frames, PCM resident in HBM) encodes at **{f(d['value'] / 1e9, 1)} G samples/s** ({f(d['ms_per_step'], 1)} ms per batch")
     if "value" in cpu:
         s += f"; {f(d['speedup_vs_cpu_1_thread'], 0)}x one host thread running the same algorithm"
-        if "all_cores" in cpu:
-            s += f", {f(d['value'] / cpu['all_cores']['value'], 0)}x all {cpu['all_cores']['cores']}"
+        if "all_cores_value" in cpu:
+            s += f", {f(d['value'] / cpu['all_cores_value'], 0)}x the {cpu['all_cores_workers']} CPUs the bench process may use"
     if "full_chip" in x:
         s += f"; {f(x['full_chip']['samples_per_s'] / 1e9, 0)} G samples/s once a batch has 4 wavefronts per SIMD"
     s += ")"
@@ -113,6 +136,10 @@ def readme_block(d, src):
         s += f"  Against the synthetic music class ({f(sc['music']['ns_per_slice'], 0)} ns per slice): " + ", ".join(parts) + "."
     if "cfg5_stream" in cfg:
         s += f"  The frame-at-a-time API on one 8-channel stream: {f(cfg['cfg5_stream']['ms_per_call'], 2)} ms per call."
+    e2e = d.get("e2e", {})
+    if "encode" in e2e:
+        s += (f"  From / to pinned host memory (one call of the host pipeline per direction): {f(e2e['encode']['samples_per_s'] / 1e9, 1)} / "
+              f"{f(e2e['decode']['samples_per_s'] / 1e9, 1)} G samples/s, PCIe-bound.")
     return s
 
 

@@ -30,10 +30,11 @@ if os.path.exists(mem):
 stats = glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
 rows = [r for r in csv.DictReader(open(stats)) if "qoa::" in r["Name"]]
-line = open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1]
-d = json.loads(line)
-tline = open(f"gpurun_out/{tag}_trace_bench.json").read().strip().splitlines()[-1]
-td = json.loads(tline)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gen_results_md import load  # noqa: E402  (the full record: the bench_extras line)
+line = open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1]   # the contract's line (<= 6 KB), quoted below
+d = load(f"gpurun_out/{tag}_bench.json")
+td = load(f"gpurun_out/{tag}_trace_bench.json")
 md = (f"# {rnd} -- rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras` (tools/prof_round.sh {tag})\n\n"
       "The kernel averages below are rocprof's over every launch of that command (warm-up and counted-plan launches included);\n"
       f"bench.py's own HIP-event figures in the same process: K1 {td['roofline']['kernel_ms_avg']:.3f} ms, "
