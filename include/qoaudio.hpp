@@ -13,9 +13,12 @@
 //   decode_all(reader)? -> DecodedQoa               decode_all(bytes)
 //   Result<_, EncodeError/DecodeError>              throws EncodeError / DecodeError (kind() = the variant)
 //
+//   (none: one clip at a time)                      HostPipeline p; p.encode(clips, pcm) / p.decode(clips, bytes): batches
+//
 // Rust's generic io::Read / io::Write cannot cross a C ABI: readers are byte buffers (or std::istream,
 // read eagerly), writers are std::vector<uint8_t> / std::ostream.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <fstream>
 #include <istream>
@@ -242,5 +245,71 @@ inline DecodedQoa open_and_decode_all(const std::string &path) {
     std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     return decode_all(b);
 }
+
+// ---- batches (no counterpart in the reference, which is one clip at a time: per clip this IS encode_all / decode_all,
+// src/lib.rs:760-763, :713-747) -- the form in which a host with many clips gets the GPU's throughput ----
+
+// One clip of a batch: pcm_offset counts int16 elements from the batch's PCM base, out_offset bytes from its encoded base.
+struct BatchClip {
+    uint64_t pcm_offset;
+    uint64_t out_offset;
+    QoaDesc desc;
+};
+
+// Contiguous layout of n identical-shape clips: PCM [n][samples][channels], encoded [n][qoa_encoded_size].
+inline std::vector<BatchClip> uniform_clips(size_t n, const QoaDesc &desc) {
+    std::vector<BatchClip> v(n);
+    const uint64_t per_pcm = (uint64_t)desc.samples * desc.channels, per_enc = qoa_encoded_size(desc.channels, desc.samples);
+    for (size_t i = 0; i < n; i++) v[i] = BatchClip{i * per_pcm, i * per_enc, desc};
+    return v;
+}
+
+// qoa_host_pipeline_*: host PCM -> host bytes and back through the time-sliced pipeline (copies overlapped with the kernels);
+// a persistent handle that keeps its streams, staging buffers and the tables of its last batch.
+class HostPipeline {
+public:
+    HostPipeline() {
+        int rc = qoa_host_pipeline_create(&h_);
+        if (rc) throw EncodeError(rc);
+    }
+    ~HostPipeline() { qoa_host_pipeline_free(h_); }
+    HostPipeline(const HostPipeline &) = delete;
+    HostPipeline &operator=(const HostPipeline &) = delete;
+
+    // encode_all per clip; `out` is sized to hold every clip's bytes at its out_offset
+    std::vector<uint8_t> encode(const std::vector<BatchClip> &clips, const std::vector<int16_t> &pcm, uint32_t chunk_frames = 0) {
+        size_t need = 0;
+        for (const BatchClip &c : clips) {
+            if ((uint64_t)c.desc.samples * c.desc.channels + c.pcm_offset > pcm.size()) throw EncodeError(EncodeError::InvalidSamples);
+            need = std::max<size_t>(need, c.out_offset + qoa_encoded_size(c.desc.channels, c.desc.samples));
+        }
+        std::vector<uint8_t> out(need);
+        std::vector<qoa_clip> cc = raw(clips);
+        int rc = qoa_host_pipeline_encode(h_, cc.data(), cc.size(), pcm.data(), out.data(), chunk_frames);
+        if (rc) throw EncodeError(rc);
+        return out;
+    }
+    // decode_all per clip (every frame header is verified on the device against the clip's desc)
+    std::vector<int16_t> decode(const std::vector<BatchClip> &clips, const std::vector<uint8_t> &enc, uint32_t chunk_frames = 0) {
+        size_t need = 0;
+        for (const BatchClip &c : clips) {
+            if (c.out_offset + qoa_encoded_size(c.desc.channels, c.desc.samples) > enc.size()) throw DecodeError(DecodeError::IoError);
+            need = std::max<size_t>(need, c.pcm_offset + (uint64_t)c.desc.samples * c.desc.channels);
+        }
+        std::vector<int16_t> pcm(need);
+        std::vector<qoa_clip> cc = raw(clips);
+        int rc = qoa_host_pipeline_decode(h_, cc.data(), cc.size(), enc.data(), pcm.data(), chunk_frames);
+        if (rc) throw DecodeError(rc);
+        return pcm;
+    }
+private:
+    static std::vector<qoa_clip> raw(const std::vector<BatchClip> &clips) {
+        std::vector<qoa_clip> cc(clips.size());
+        for (size_t i = 0; i < clips.size(); i++)
+            cc[i] = qoa_clip{clips[i].pcm_offset, clips[i].out_offset, qoa_desc{clips[i].desc.channels, clips[i].desc.sample_rate, clips[i].desc.samples}};
+        return cc;
+    }
+    qoa_host_pipeline *h_ = nullptr;
+};
 
 } // namespace qoaudio

@@ -191,6 +191,31 @@ static void test_bench_item_count() {
     CHECK(count == 2394122u * 2 + 468);
 }
 
+// (not a reference test: the reference encodes one clip at a time.)  A batch of clips cut from the fixture through the host
+// pipeline must equal encode_all per clip (src/lib.rs:760-763) byte for byte, and its decode must equal decode_all of those bytes.
+static void test_host_pipeline_batch_equals_per_clip_calls() {
+    auto original = decode_all(QOA_BYTES);
+    const size_t channels = original.num_channels, n_clips = 12;
+    const uint32_t samples = 3 * QOA_FRAME_LEN + 1234;
+    QoaDesc desc{original.num_channels, original.sample_rate, samples};
+    auto clips = uniform_clips(n_clips, desc);
+    std::vector<int16_t> pcm(n_clips * samples * channels);
+    for (size_t i = 0; i < n_clips; i++)
+        std::memcpy(&pcm[clips[i].pcm_offset], &original.samples[i * 150000 * channels], samples * channels * sizeof(int16_t));
+    HostPipeline pipe;
+    auto enc = pipe.encode(clips, pcm);
+    auto back = pipe.decode(clips, enc);
+    const size_t per_enc = qoa_encoded_size(desc.channels, desc.samples);
+    CHECK(enc.size() == n_clips * per_enc && back.size() == pcm.size());
+    for (size_t i = 0; i < n_clips; i++) {
+        std::vector<int16_t> one(pcm.begin() + clips[i].pcm_offset, pcm.begin() + clips[i].pcm_offset + samples * channels);
+        auto want = encode_all(one, desc);
+        CHECK(want.size() == per_enc && std::memcmp(want.data(), &enc[clips[i].out_offset], per_enc) == 0);
+        auto dec = decode_all(want);
+        CHECK(dec.samples.size() == one.size() && std::memcmp(dec.samples.data(), &back[clips[i].pcm_offset], one.size() * 2) == 0);
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { std::printf("usage: %s fixture.qoa\n", argv[0]); return 2; }
     std::ifstream f(argv[1], std::ios::binary);
@@ -206,6 +231,7 @@ int main(int argc, char **argv) {
     run("test_full_file_round_trip", test_full_file_round_trip);
     run("test_streaming_encode", test_streaming_encode);
     run("test_bench_item_count", test_bench_item_count);
+    run("test_host_pipeline_batch_equals_per_clip_calls", test_host_pipeline_batch_equals_per_clip_calls);
     std::printf("%d failure(s)\n", failures);
     return failures ? 1 : 0;
 }

@@ -114,7 +114,7 @@ def test_cpp_mirror_runs_the_reference_suite(gpu, tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "qoaudio_amd")])
     r = subprocess.run([str(exe), FIXTURE], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("ok   test_") == 10
+    assert r.stdout.count("ok   test_") == 11  # the crate's 10 + the batch wrapper (HostPipeline) against per-clip calls
 
 
 def test_wav_cli_round_trip(gpu, oracle, tmp_path):
