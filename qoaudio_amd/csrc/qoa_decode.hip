@@ -856,7 +856,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     constexpr int sl = decltype(sc)::value;
                     static_for<0, NLS>([&](auto oc) {
                         constexpr int o = decltype(oc)::value;
-                        // always issued (the static vmcnt bookkeeping of the slice loads counts it), lanes without a complete line off
+                        // always issued (the static vmcnt bookkeeping of the slice loads counts it), lanes without a complete line
+                        // off -- possibly ALL lanes: a store under EXEC = 0 still passes through the vmcnt order (measured:
+                        // tools/ubench/exec0_vmcnt.hip, profiles/r05_ubench_gfx950_exec0_vmcnt.txt -- behind [cold load, 4 stores
+                        // with EXEC = 0] `s_waitcnt vmcnt(4)` lasts as long as behind 4 real stores, 248 vs 249 ticks; 56 with nothing)
                         unsigned long long keep;
                         const unsigned long long a_ = ga[sl][o], m_ = ok_mask[sl][o]; // (copies: an asm operand alone does not
                         const u4_unaligned v_ = vv[sl][o];                            // capture the enclosing lambda's arrays)
