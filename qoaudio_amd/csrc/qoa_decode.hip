@@ -164,6 +164,7 @@ __device__ __forceinline__ void init_mag_table(uint2 *s_mags) {
     __syncthreads();
 }
 
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 1 // (the generic kernel: part 1 of the object; see the launchers)
 // K2 generic: any channel count (1..255), one lane per chain, direct 2-byte global stores.  Used for the
 // exotic streams only (more than 8 channels); everything else goes through qoa_decode_frames_kernel.
 __global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restrict__ in, int16_t *__restrict__ out,
@@ -204,6 +205,8 @@ __global__ void __launch_bounds__(256) qoa_decode_kernel(const uint8_t *__restri
     }
 }
 
+#endif // part 1
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 1 || QOA_DECODE_PART == 4 // (the general kernel: its whole-piece / PARTIAL variants)
 // K2: NCH in 1..8, one table entry per FRAME, 64/NCH frames per wavefront, LDS-transposed output.
 // `scratch` points at kDecodeScratchBytes of device memory that absorbs the 16-byte stores of pieces that lie
 // beyond a frame's end: making every flush store unconditional keeps their count static, so hipcc can wait
@@ -424,6 +427,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
     }
 }
 
+#endif // part 1
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART >= 2 // (the K2u kernel template: parts 2 and 3 instantiate different channel counts)
 // ------------------------------------------------------------------------------------------------
 // K2u: the fast path for UNIFORM frames -- rows == 256 and n_out == 5120 (every frame of a clip but its last), 1 .. 8
 // channels (round 4: also 3 / 5 / 6 / 7, whose frames do not fill a wavefront: K2uCfg, "mirror" lanes), PCM on a dword grid
@@ -1001,9 +1006,16 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
 }
 
 
+#endif // parts 2 and 3
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
+// The object is built in four parts side by side (hipcc spends 2.5 minutes on this file as one unit): qoa_decode.o =
+// QOA_DECODE_PART 1, the general kernels and their launchers; qoa_decode_u.o (qoa_decode_u.hip) = part 2, K2u for 1 / 2 / 4 / 8
+// channels + the absolute-line variant; qoa_decode_v.o = part 3, K2u for 3 / 5 / 6 / 7 channels; qoa_decode_w.o = part 4, the general
+// kernel's PARTIAL variants.  Without
+// the macro (tools/k2lab/build_lib.sh) the file is one unit with everything.
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 1
 hipError_t launch_decode(const uint8_t *in, int16_t *out, const DecChain *chains, unsigned n, unsigned *mismatches,
                          hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -1012,6 +1024,8 @@ hipError_t launch_decode(const uint8_t *in, int16_t *out, const DecChain *chains
     return hipGetLastError();
 }
 
+#endif // part 1
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 1 || QOA_DECODE_PART == 4
 template <int R, int WPB, bool PARTIAL>
 static hipError_t launch_decode_frames_r(int nch, const uint8_t *in, int16_t *out, const DecChain *frames,
                                          unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
@@ -1032,6 +1046,8 @@ static hipError_t launch_decode_frames_r(int nch, const uint8_t *in, int16_t *ou
     return hipGetLastError();
 }
 
+#endif // part 1
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART >= 2
 template <int NCH, bool ABS = false>
 static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
                                           unsigned *mismatches, hipStream_t stream) {
@@ -1056,19 +1072,33 @@ static hipError_t launch_decode_uniform_n(const uint8_t *in, int16_t *out, const
     return hipGetLastError();
 }
 
+#endif // parts 2 and 3: the launcher template
+// (part 3 of the object, qoa_decode_v.hip: the channel counts that do not divide a wavefront -- their 16-row rounds make them
+// the slowest instantiations to compile)
+hipError_t launch_decode_uniform_odd(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
+                                     unsigned *mismatches, hipStream_t stream);
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 3
+hipError_t launch_decode_uniform_odd(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
+                                     unsigned *mismatches, hipStream_t stream) {
+    switch (nch) {
+    case 3: return launch_decode_uniform_n<3>(in, out, frames, n_frames, mismatches, stream);
+    case 5: return launch_decode_uniform_n<5>(in, out, frames, n_frames, mismatches, stream);
+    case 6: return launch_decode_uniform_n<6>(in, out, frames, n_frames, mismatches, stream);
+    case 7: return launch_decode_uniform_n<7>(in, out, frames, n_frames, mismatches, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 2
 hipError_t launch_decode_uniform(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
                                  unsigned *mismatches, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
     switch (nch) {
     case 1: return launch_decode_uniform_n<1>(in, out, frames, n_frames, mismatches, stream);
     case 2: return launch_decode_uniform_n<2>(in, out, frames, n_frames, mismatches, stream);
-    case 3: return launch_decode_uniform_n<3>(in, out, frames, n_frames, mismatches, stream);
     case 4: return launch_decode_uniform_n<4>(in, out, frames, n_frames, mismatches, stream);
-    case 5: return launch_decode_uniform_n<5>(in, out, frames, n_frames, mismatches, stream);
-    case 6: return launch_decode_uniform_n<6>(in, out, frames, n_frames, mismatches, stream);
-    case 7: return launch_decode_uniform_n<7>(in, out, frames, n_frames, mismatches, stream);
     case 8: return launch_decode_uniform_n<8>(in, out, frames, n_frames, mismatches, stream);
-    default: return hipErrorInvalidValue;
+    default: return launch_decode_uniform_odd(nch, in, out, frames, n_frames, mismatches, stream);
     }
 }
 
@@ -1081,17 +1111,27 @@ hipError_t launch_decode_uniform_abs(int nch, const uint8_t *in, int16_t *out, c
     }
 }
 
+#endif // part 2
+hipError_t launch_decode_frames_partial(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
+                                        unsigned *mismatches, uint8_t *scratch, hipStream_t stream);
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 1
 hipError_t launch_decode_frames(int nch, bool whole_pieces, const uint8_t *in, int16_t *out, const DecChain *frames,
                                 unsigned n_frames, unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
+    if (!whole_pieces) return launch_decode_frames_partial(nch, in, out, frames, n_frames, mismatches, scratch, stream);
     // few wavefronts (the short last frames of a batch): one per workgroup, so that they spread over the compute units
     const unsigned waves = (n_frames + (64u / (unsigned)nch) - 1) / (64u / (unsigned)nch);
-    if (waves < 1024u) {
-        if (whole_pieces) return launch_decode_frames_r<4, 1, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
-        return launch_decode_frames_r<4, 1, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
-    }
-    if (whole_pieces) return launch_decode_frames_r<4, 4, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
+    if (waves < 1024u) return launch_decode_frames_r<4, 1, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
+    return launch_decode_frames_r<4, 4, false>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
+}
+#endif // part 1
+#if !defined(QOA_DECODE_PART) || QOA_DECODE_PART == 4
+// (part 4, qoa_decode_w.hip: the PARTIAL variants -- frames whose PCM is no whole number of 16-byte pieces)
+hipError_t launch_decode_frames_partial(int nch, const uint8_t *in, int16_t *out, const DecChain *frames, unsigned n_frames,
+                                        unsigned *mismatches, uint8_t *scratch, hipStream_t stream) {
+    const unsigned waves = (n_frames + (64u / (unsigned)nch) - 1) / (64u / (unsigned)nch);
+    if (waves < 1024u) return launch_decode_frames_r<4, 1, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
     return launch_decode_frames_r<4, 4, true>(nch, in, out, frames, n_frames, mismatches, scratch, stream);
 }
-
+#endif // part 4
 } // namespace qoa
