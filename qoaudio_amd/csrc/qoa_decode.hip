@@ -765,12 +765,12 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             if constexpr (row % HR == 0)
                 unit_top(std::integral_constant<int, row / HR>{}, round * UNITS + row / HR);
             {
-                static_assert(ABS || RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 3 ? QOA_DEC_ASM_RING_3
+                static_assert(ABS || (RING == (NCH == 1 ? QOA_DEC_ASM_RING_1 : NCH == 2 ? QOA_DEC_ASM_RING_2 : NCH == 3 ? QOA_DEC_ASM_RING_3
                                        : NCH == 4 ? QOA_DEC_ASM_RING_4 : NCH == 5 ? QOA_DEC_ASM_RING_5 : NCH == 6 ? QOA_DEC_ASM_RING_6
                                        : NCH == 7 ? QOA_DEC_ASM_RING_7 : QOA_DEC_ASM_RING_8) &&
                                   RR == (NCH == 1 ? QOA_DEC_ASM_ROWS_1 : NCH == 2 ? QOA_DEC_ASM_ROWS_2 : NCH == 3 ? QOA_DEC_ASM_ROWS_3
                                          : NCH == 4 ? QOA_DEC_ASM_ROWS_4 : NCH == 5 ? QOA_DEC_ASM_ROWS_5 : NCH == 6 ? QOA_DEC_ASM_ROWS_6
-                                         : NCH == 7 ? QOA_DEC_ASM_ROWS_7 : QOA_DEC_ASM_ROWS_8),
+                                         : NCH == 7 ? QOA_DEC_ASM_ROWS_7 : QOA_DEC_ASM_ROWS_8)),
                               "generated image offsets");
                 static_assert(!ABS || (RING == QOA_DEC_ASM_ABS_RING_2 && C::MIRROR == QOA_DEC_ASM_ABS_MIRROR_2 && RR == QOA_DEC_ASM_ROWS_2),
                               "generated image offsets (absolute-line rows)");
@@ -837,7 +837,6 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
                 typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(4)));
                 asm volatile("" ::: "memory"); // the image was written as int16: keep the reads below behind those stores
-                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO);
                 u4_unaligned vv[C::ABS_SLOTS][NLS];
                 unsigned long long ga[C::ABS_SLOTS][NLS], ok_mask[C::ABS_SLOTS][NLS];
                 const unsigned frame_img = (lane / (unsigned)LPL) * GSP;
@@ -856,6 +855,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     });
                 });
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the issue priority is raised for the store burst only (as in the aligned kernel), not for the line bookkeeping in
+                // front of it: 1-2 % on under-filled launches (profiles/r05_k2u_offgrid_prio.txt)
+                if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(C::FLUSH_PRIO);
                 asm volatile("; K2u absolute-line flush, streamed stores" ::: "memory");
                 static_for<0, C::ABS_SLOTS>([&](auto sc) {
                     constexpr int sl = decltype(sc)::value;

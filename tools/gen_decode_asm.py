@@ -217,7 +217,7 @@ def render():
                ""]
     n_lines = 0
     for nch, (rows, ring_bytes) in sorted(GEOMETRY.items()):
-        assert ring_bytes % 64 == 0 and (nch == 1 or (ring_bytes % 128 == 0 and ring_bytes % (2 * nch) == 0)), (nch, ring_bytes)
+        assert ring_bytes % (32 if nch == 1 else 64) == 0 and (nch == 1 or (ring_bytes % 128 == 0 and ring_bytes % (2 * nch) == 0)), (nch, ring_bytes)
         for row in range(rows):
             t = row_text(nch, row, ring_bytes)
             check_hazards(t)
