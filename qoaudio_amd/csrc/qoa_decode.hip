@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_frames_kernel(const uint8
 template <int NCH, bool ABS = false>
 struct K2uCfg {
     static constexpr bool POW2 = (NCH & (NCH - 1)) == 0; // 1, 2, 4, 8: the channels of a frame fill whole wavefronts
-    static_assert(!ABS || NCH == 2, "absolute-line rows are generated for stereo (tools/gen_decode_asm.py: GEOMETRY_ABS)");
+    static_assert(!ABS || NCH == 2 || NCH == 4 || NCH == 8, "absolute-line rows are generated for 2 / 4 / 8 channels (tools/gen_decode_asm.py: GEOMETRY_ABS)");
     // bytes per flushed "line" and lanes per line.  128 / 8 everywhere in the product; the lab's mono variant (QOA_K2U_MONO_HALF:
     // 64-byte half lines, a 128-byte ring per frame -> 12 instead of 8 wavefronts per CU) is measured in profiles/r04_k2lab_log.md
 #ifdef QOA_K2U_MONO_HALF
@@ -509,7 +509,10 @@ struct K2uCfg {
 #ifndef QOA_K2G_PR // (tools/k2lab: rows per phase of the 3 / 5 / 6 / 7-channel geometry)
 #define QOA_K2G_PR 2
 #endif
-    static constexpr int PR = NCH == 1 ? (LNB == 64 ? 2 : 4) : NCH == 2 ? 2 : POW2 ? (RR < 4 ? RR : 4) : QOA_K2G_PR; // rows per phase (flush granularity)
+    // rows per phase (flush granularity).  ABS at 4 / 8 channels: half a round (320 bytes) instead of the whole one, so that a phase
+    // + the longest unfinished line (127 bytes) fit the 640-byte ring
+    static constexpr int PR = ABS ? (NCH == 8 ? 1 : 2)
+                                  : NCH == 1 ? (LNB == 64 ? 2 : 4) : NCH == 2 ? 2 : POW2 ? (RR < 4 ? RR : 4) : QOA_K2G_PR;
     static constexpr int PB = PR * 40 * NCH;             // PCM bytes per frame per phase
     static constexpr int ring() { // whole lines, >= one phase + the largest carried partial line, and a whole number of
                                   // sample-times (2 NCH bytes): a lane's channel offset is added to a wrapped sample-time offset,
@@ -530,7 +533,9 @@ struct K2uCfg {
     // Otherwise RING + 16: the flush reads whole 16-byte pieces with ONE ds_read_b128 each (4 x ds_read_b32 before), and the
     // 2-byte scatter of a half-wave (at most 16 frames, stride 17 or 41 sixteen-byte units) meets at most 2 frames per bank,
     // which a ds_write hides behind its own data transfer (MI355X_MICROARCH.md, LDS: "2-way on ds_write_b32 costs nothing").
-    static constexpr int MIRROR = ABS ? 8 : 0; // bytes of the ring's start written again behind its end (generated rows)
+    // bytes of the ring's start written again behind its end (generated rows): 8 are needed (a frame may sit 8 bytes off the
+    // 16-byte grid even at 8 channels: offsets count int16 elements), whole sample-times are written
+    static constexpr int MIRROR = ABS ? (NCH == 8 ? 16 : 8) : 0;
 #ifdef QOA_K2U_GSP_PAD
     static constexpr int GSP = RING + QOA_K2U_GSP_PAD;
 #else
@@ -772,7 +777,8 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                                          : NCH == 4 ? QOA_DEC_ASM_ROWS_4 : NCH == 5 ? QOA_DEC_ASM_ROWS_5 : NCH == 6 ? QOA_DEC_ASM_ROWS_6
                                          : NCH == 7 ? QOA_DEC_ASM_ROWS_7 : QOA_DEC_ASM_ROWS_8)),
                               "generated image offsets");
-                static_assert(!ABS || (RING == QOA_DEC_ASM_ABS_RING_2 && C::MIRROR == QOA_DEC_ASM_ABS_MIRROR_2 && RR == QOA_DEC_ASM_ROWS_2),
+                static_assert(!ABS || (RING == (NCH == 2 ? QOA_DEC_ASM_ABS_RING_2 : NCH == 4 ? QOA_DEC_ASM_ABS_RING_4 : QOA_DEC_ASM_ABS_RING_8) &&
+                                       C::MIRROR == (NCH == 2 ? QOA_DEC_ASM_ABS_MIRROR_2 : NCH == 4 ? QOA_DEC_ASM_ABS_MIRROR_4 : QOA_DEC_ASM_ABS_MIRROR_8)),
                               "generated image offsets (absolute-line rows)");
                 const uint2 raw = unit_raw[row % HR];
                 unsigned force = 0, flag = 0;
@@ -1109,6 +1115,8 @@ hipError_t launch_decode_uniform_abs(int nch, const uint8_t *in, int16_t *out, c
     if (n_frames == 0) return hipSuccess;
     switch (nch) {
     case 2: return launch_decode_uniform_n<2, true>(in, out, frames, n_frames, mismatches, stream);
+    case 4: return launch_decode_uniform_n<4, true>(in, out, frames, n_frames, mismatches, stream);
+    case 8: return launch_decode_uniform_n<8, true>(in, out, frames, n_frames, mismatches, stream);
     default: return hipErrorInvalidValue;
     }
 }

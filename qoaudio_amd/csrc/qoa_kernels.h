@@ -63,7 +63,7 @@ hipError_t launch_decode_uniform(int nch, const uint8_t *d_in, int16_t *d_out, c
 // K2u's absolute-line variant (round 5): uniform frames whose PCM address is off the 128-byte grid but a multiple of 8 -- the
 // flush works on the frame's absolute cache lines (whole-line streamed stores; the frame's first and last line partial).
 // Also correct, just not needed, for frames on the grid.  decode_uniform_abs_supported(nch): the channel counts it is built for.
-constexpr bool decode_uniform_abs_supported(int nch) { return nch == 2; }
+constexpr bool decode_uniform_abs_supported(int nch) { return nch == 2 || nch == 4 || nch == 8; }
 hipError_t launch_decode_uniform_abs(int nch, const uint8_t *d_in, int16_t *d_out, const DecChain *d_frames, unsigned n_frames,
                                      unsigned *d_mismatches, hipStream_t stream);
 

@@ -1200,9 +1200,10 @@ def test_wave_stats_tell_what_a_batch_cost(gpu, oracle):
         batch.EncodePlan(clips).wave_stats()
 
 
+@pytest.mark.parametrize("channels", [2, 4, 8])
 @pytest.mark.parametrize("n_streams", [3, 70])
-def test_k2u_absolute_line_flush_at_every_offset(gpu, oracle, n_streams):
-    """K2u's absolute-line variant (round 5; stereo): full frames whose PCM is off the 128-byte grid but on the 8-byte grid are
+def test_k2u_absolute_line_flush_at_every_offset(gpu, oracle, n_streams, channels):
+    """K2u's absolute-line variant (round 5; 2 / 4 / 8 channels): full frames whose PCM is off the 128-byte grid but on the 8-byte grid are
     flushed as whole ABSOLUTE cache lines -- the frame's first and last line partial, 8 single bytes at either end where the
     address is no multiple of 16.  Streams of 2 .. 5 full frames (music, hostile headers + all-ones slices that take the 32-bit
     rows, random garbage) at PCM offsets that run through EVERY multiple of 4 bytes modulo 128 (offsets that are 4 mod 8 stay on
@@ -1212,8 +1213,7 @@ def test_k2u_absolute_line_flush_at_every_offset(gpu, oracle, n_streams):
     one wavefront per workgroup; 70: four, several workgroups).  Sample for sample against the oracle's decoder
     (src/lib.rs:291-330)."""
     from qoaudio_amd import batch
-    channels = 2
-    r = np.random.default_rng(77 + n_streams)
+    r = np.random.default_rng(77 + n_streams + 1000 * channels)
     fs = 8 + 16 * channels + 8 * 256 * channels
     streams, n_frames = [], []
     music = oracle.encode_all(rng_pcm(31, 5 * 5120 * channels), channels, 44100, 5 * 5120)

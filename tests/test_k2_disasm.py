@@ -186,7 +186,11 @@ def test_k2u_flush_stores_issue_at_raised_priority(kernels):
             # the absolute-line variant (round 5): whole absolute lines only, every line store streamed and under a lane mask
             # (always issued: the static vmcnt count of the slice loads includes it) -- all but the frame's last line, which goes
             # out behind the loop, inside the raised-priority window
-            assert nt > 0 and wb == 0 and raised_stores == 8 * plain_stores and raised_stores + plain_stores == nt, (name, nt, wb, raised_stores, plain_stores)  # (stereo: 4 phases x 2 slots per round; the last line once)
+            # per round: phases x store slots x role groups (2 ch: 4 x 2 x 4, 4 ch: 2 x 3 x 2, 8 ch: 2 x 3 x 1), all at raised priority
+            # (8 ch: no priority window at all); the frame's last line once per role group, behind the loop
+            per_round, groups = {2: (32, 4), 4: (12, 2), 8: (6, 1)}[nch]
+            assert nt == per_round + groups and wb == 0, (name, nt, wb)
+            assert (raised_stores, plain_stores) == ((0, nt) if nch == 8 else (per_round, groups)), (name, raised_stores, plain_stores)
             for k, i in enumerate(ins):
                 if i.split()[0] in ("global_store_dwordx4", "global_store_dwordx2"):
                     assert re.match(r"s_and_b64 exec, exec, s\[\d+:\d+\]", ins[k - 1]), (name, ins[k - 2:k + 2])

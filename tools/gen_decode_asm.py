@@ -197,7 +197,7 @@ GEOMETRY = {1: (16, int(os.environ.get("QOA_DEC_RING1", "256"))), 2: (8, int(os.
 # are written a second time behind its end (the sample's lane issues a second ds_write: 2 of 80 per ring revolution) and every
 # piece is 16 contiguous bytes.  The ring divides the round's bytes (640), so that the bytes a round leaves behind for the next
 # round's first line sit where that line's pieces look for them.  Must agree with K2uCfg<NCH, true> in qoa_decode.hip.
-GEOMETRY_ABS = {2: (8, 320, 8)}
+GEOMETRY_ABS = {2: (8, 320, 8), 4: (4, 640, 8), 8: (2, 640, 16)}   # (8 channels: the first whole sample-time, 16 bytes; 8 are needed)
 
 
 def render():
@@ -224,7 +224,7 @@ def render():
             n_lines = len(t)
             out.append(emit(f"QOA_DEC_ROW_TEXT_{nch}_{row}", t))
     for nch, (rows, ring_bytes, mirror) in sorted(GEOMETRY_ABS.items()):
-        assert nch > 1 and (rows * 40 * nch) % ring_bytes == 0 and ring_bytes % (2 * nch) == 0 and mirror % (2 * nch) == 0
+        assert nch > 1 and (rows * 40 * nch) % ring_bytes == 0 and ring_bytes % (2 * nch) == 0 and mirror % (2 * nch) == 0 and mirror >= 8
         for row in range(rows):
             t = row_text(nch, row, ring_bytes, mirror)
             check_hazards(t)

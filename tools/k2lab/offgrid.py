@@ -2,7 +2,7 @@
 """K2u on full-size batches whose PCM is off the 128-byte grid (round 5: the absolute-line variant): 1024 stereo clips x FRAMES
 frames, every clip's PCM shifted by DELTA bytes from the grid (clip stride padded to whole lines, so every frame of the batch
 has the same delta).  Kernel ms by HIP events, best of 5 behind a warm-up; fraction of the 8 TB/s peak; PCM against delta = 0.
-    python tools/k2lab/offgrid.py [frames=256] [deltas=0,16,48,8,40,120,4]"""
+    python tools/k2lab/offgrid.py [frames=256] [deltas=0,16,48,8,40,120,4] [channels=2]"""
 import os
 import sys
 
@@ -23,7 +23,8 @@ L._lib = libs["product"]
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 deltas = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,16,48,8,40,120,4").split(",")]
-n_clips, ch = 1024, 2
+ch = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+n_clips = 2048 // ch
 samples = frames * 5120
 desc = gpu.QoaDesc(ch, 44100, samples)
 clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
