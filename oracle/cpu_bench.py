@@ -112,12 +112,17 @@ def all_cores_leg(workers, seconds):
     procs = [ctx.Process(target=_worker, args=(i, workers, seconds, ready, go, results)) for i in range(workers)]
     for p in procs:
         p.start()
-    for _ in procs:
-        ready.acquire()
-    go.set()
-    got = [results.get() for _ in procs]
-    for p in procs:
-        p.join()
+    try:
+        for _ in procs:
+            if not ready.acquire(timeout=120):
+                raise RuntimeError("an all-cores worker did not come up")
+        go.set()
+        got = [results.get(timeout=seconds * 20 + 120) for _ in procs]  # (a worker that died must not hang the bench)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()  # the exact processes started above
     clips = sum(n for _, n, _ in got)
     wall = max(dt for _, _, dt in got)
     return clips, wall, min(dt for _, _, dt in got)

@@ -225,8 +225,11 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
         }
         hipError_t e = g->chains.reserve(v.size() * sizeof(EncChain));
         if (e == hipSuccess) e = g->lms.reserve(v.size() * 8 * sizeof(int32_t));
-        if (e == hipSuccess && (flags & QOA_PLAN_WAVE_STATS))
-            e = g->wave_rec.reserve((size_t)((v.size() + 3) / 4) * kWaveRecWords * sizeof(uint32_t));
+        if (e == hipSuccess && (flags & QOA_PLAN_WAVE_STATS)) {
+            const size_t rec_bytes = (size_t)((v.size() + 3) / 4) * kWaveRecWords * sizeof(uint32_t);
+            e = g->wave_rec.reserve(rec_bytes);
+            if (e == hipSuccess) e = hipMemset(g->wave_rec.p, 0, rec_bytes); // (a plan that never ran reports no wavefronts)
+        }
         if (e == hipSuccess) e = hipMemcpy(g->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             delete plan;
