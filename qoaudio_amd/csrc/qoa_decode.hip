@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
     // unflushed absolute line (128 (m + 1) - delta), rp = ring offset of this lane's piece of that line; the piece's address is
     // out_ptr[o] + lend (out_ptr[o] = frame address + 16 q - 128, advanced by the round's bytes per round like the aligned
     // kernel's).  f_lo[o] = the frame's address: pieces of its first line that lie in front of it are not written.
-    int lend[NLS];
+    unsigned lend[NLS]; // (always positive: 1 .. the round's bytes + 128)
     unsigned rp[NLS], edge_q[NLS];
     unsigned long long f_lo[NLS];
     (void)lend; (void)rp; (void)edge_q; (void)f_lo;
@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             const unsigned long long fa = out_ptr[o] - (lane % (unsigned)LPL) * 16u; // the role's frame address
             const unsigned delta = (unsigned)fa & 127u;
             f_lo[o] = fa;
-            lend[o] = 128 - (int)delta;
+            lend[o] = 128u - delta;
             rp[o] = (unsigned)(RING - (int)delta + 16 * (int)(lane % (unsigned)LPL)) % (unsigned)RING; // piece q of the line that ends at lend
             // the piece that straddles the frame's start (and, 20480 NCH bytes on, its end) when delta is no multiple of 16:
             // this lane's if q == delta / 16; 8 = none
@@ -840,8 +840,10 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
             if constexpr (ABS && (row + 1) % PR == 0) {
                 // ---- absolute-line flush: the lines of every frame that are complete now, as whole cache lines ----
                 constexpr int P = (row + 1) * 40 * NCH; // bytes of the round written so far
-                typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
-                typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(4)));
+                // (pieces sit on an 8-byte grid in the ring: one ds_read_b128 each -- as 4-byte aligned vectors hipcc read them
+                // with two ds_read2_b32 and an address add apiece)
+                typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(8)));
+                typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(8)));
                 asm volatile("" ::: "memory"); // the image was written as int16: keep the reads below behind those stores
                 u4_unaligned vv[C::ABS_SLOTS][NLS];
                 unsigned long long ga[C::ABS_SLOTS][NLS], ok_mask[C::ABS_SLOTS][NLS];
@@ -850,14 +852,15 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     constexpr int sl = decltype(sc)::value;
                     static_for<0, NLS>([&](auto oc) {
                         constexpr int o = decltype(oc)::value;
-                        const bool valid = lend[o] <= P; // the frame's next line is complete
+                        const bool valid = lend[o] <= (unsigned)P; // the frame's next line is complete
                         vv[sl][o] = *(const u4_unaligned *)(img + frame_img + o * FPS * GSP + rp[o]);
-                        ga[sl][o] = out_ptr[o] + (unsigned long long)(long long)lend[o];
-                        // (a piece of the frame's first line that lies in front of the frame, or straddles its start, is not written)
-                        ok_mask[sl][o] = __builtin_amdgcn_ballot_w64(valid && ga[sl][o] >= f_lo[o]);
+                        ga[sl][o] = out_ptr[o] + lend[o];
+                        // (a piece of the frame's first line that lies in front of the frame, or straddles its start, is not written;
+                        // two ballots and a scalar AND: the ballot of the combined condition costs two VALU more)
+                        ok_mask[sl][o] = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(ga[sl][o] >= f_lo[o]);
                         const unsigned rn = rp[o] + (unsigned)LNB;
                         rp[o] = valid ? min(rn, rn - (unsigned)RING) : rp[o]; // (+ 128) mod RING
-                        lend[o] += valid ? LNB : 0;
+                        lend[o] += valid ? (unsigned)LNB : 0u;
                     });
                 });
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -899,7 +902,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 }
                 if constexpr (row + 1 == RR) {
 #pragma unroll
-                    for (int o = 0; o < NLS; o++) lend[o] -= RR * 40 * NCH; // the next round counts from its own start
+                    for (int o = 0; o < NLS; o++) lend[o] -= (unsigned)(RR * 40 * NCH); // the next round counts from its own start
                 }
                 asm volatile("; end of the absolute-line burst" ::: "memory");
                 if constexpr (C::FLUSH_PRIO != 0) __builtin_amdgcn_s_setprio(0);
@@ -993,15 +996,15 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
         // ---- the frame's last line: what is left in the ring (delta bytes).  lend counts from the frame's END now: this lane's
         // piece starts at lend - 128 + 16 q <= 0; whole pieces in front of the end go out as one masked line, the piece that
         // straddles the end (delta no multiple of 16) gives its first 8 bytes ----
-        typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
-        typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(4)));
+        typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(8)));
+        typedef unsigned u2_unaligned __attribute__((ext_vector_type(2), aligned(8)));
         asm volatile("" ::: "memory");
         const unsigned frame_img = (lane / (unsigned)LPL) * GSP;
         static_for<0, NLS>([&](auto oc) {
             constexpr int o = decltype(oc)::value;
-            const int start = lend[o] - LNB + 16 * (int)(lane % (unsigned)LPL);
+            const int start = (int)lend[o] - LNB + 16 * (int)(lane % (unsigned)LPL);
             const u4_unaligned v = *(const u4_unaligned *)(img + frame_img + o * FPS * GSP + rp[o]);
-            const unsigned long long a = out_ptr[o] + (unsigned long long)(long long)lend[o];
+            const unsigned long long a = out_ptr[o] + lend[o];
             const unsigned long long m16 = __builtin_amdgcn_ballot_w64(start + 16 <= 0);
             const unsigned long long m8 = __builtin_amdgcn_ballot_w64(start == -8);
             const u2_unaligned v8 = u2_unaligned{v[0], v[1]};
