@@ -404,7 +404,11 @@ int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips, qoa_decode
 void qoa_decode_plan_free(qoa_decode_plan *plan);
 int qoa_decode_plan_bytes(const qoa_decode_plan *plan, uint64_t *in_bytes, uint64_t *pcm_bytes,
                           uint64_t *samples_i16);
-/* Enqueue the decode on `stream`.  d_in / d_out are DEVICE pointers.  Asynchronous. */
+/* Enqueue the decode on `stream`.  d_in / d_out are DEVICE pointers.  Asynchronous.
+ * Layout and speed: full frames (5120 sample-times) whose PCM address is a multiple of 128 bytes decode at the full rate; for 2, 4
+ * and 8 channels so do frames off that grid on an 8-byte grid (the kernel's absolute-line variant, ~0.9-1.0x) PROVIDED d_out
+ * itself is 128-byte aligned (any hipMalloc is): offsets were classified against it when the plan was built; other dword-aligned
+ * frames take write-back stores (about half the rate), short last frames and PCM off the dword grid the general kernel. */
 int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream);
 /* After synchronising: number of frames whose header on the device disagreed with the plan in the LAST run
  * (from_clips plans only; 0 for a well-formed batch). */
