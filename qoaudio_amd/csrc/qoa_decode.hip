@@ -496,8 +496,8 @@ struct K2uCfg {
     // rows per round: the fewest whose PCM is whole 128-byte lines of every frame (40 NCH bytes per row):
     // 1 / 2 / 4 / 8 channels 16 / 8 / 4 / 2 rows = 640 B; 6 channels 8 rows = 1920 B; 3 / 5 / 7 channels 16 rows
     static constexpr int RR = 16 / gcd16();
-#ifdef QOA_K2U_HR2
-    static constexpr int HR = NCH == 2 ? QOA_K2U_HR2 : NCH == 1 ? 4 : RR;
+#ifdef QOA_K2U_HR2 // (tools/k2lab: rows per staging unit of the stereo geometry)
+    static constexpr int HR = NCH == 2 ? QOA_K2U_HR2 : NCH == 1 ? 4 : POW2 ? RR : 4;
 #else
     // rows per staging unit.  3 / 5 / 6 / 7 channels: 4 rows = 32 NCH bytes per frame and request (round 4; 2 rows -- one load
     // instruction per unit -- were 2 .. 3.5 % slower on all four, 8 rows 1 .. 3 % slower: profiles/r04_k2lab_log.md section 7)
@@ -911,7 +911,9 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                 // flush the lines this phase completed
                 constexpr int l0 = C::lines_done(row + 1 - PR), l1 = C::lines_done(row + 1);
                 typedef unsigned u4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
-                typedef unsigned u4_piece __attribute__((ext_vector_type(4), aligned(16), may_alias));
+                typedef unsigned u4_piece16 __attribute__((ext_vector_type(4), aligned(16), may_alias));
+                typedef unsigned u4_piece8 __attribute__((ext_vector_type(4), aligned(8), may_alias));
+                typedef std::conditional_t<GSP % 16 == 0, u4_piece16, u4_piece8> u4_piece;
                 typedef unsigned u32_alias __attribute__((may_alias));
                 asm volatile("" ::: "memory"); // the image was written as int16: keep the dword reads below behind those stores
                 // The flushing wavefront issues ahead of the SIMD's other wavefronts (s_setprio): its LDS reads and line stores go
@@ -928,7 +930,7 @@ __global__ void __launch_bounds__(64 * WPB) qoa_decode_uniform_kernel(const uint
                     constexpr int o = decltype(oc)::value;
 #pragma unroll
                     for (int ln = l0; ln < l1; ln++) {
-                        if constexpr (GSP % 16 == 0) {
+                        if constexpr (GSP % 8 == 0) { // (16-byte aligned in the product; the lab's 8-byte ring pads read unaligned)
                             const u4_piece x = *(const u4_piece *)(img + oct_img + o * FPS * GSP + (ln * LNB) % RING);
                             vv[o][ln - l0] = u4_unaligned{x[0], x[1], x[2], x[3]};
                         } else {
