@@ -82,7 +82,7 @@ def build(force=False):
     """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
-    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
     return LIB_PATH
 
 

@@ -91,7 +91,7 @@ def pytest_sessionstart(session):
     srcs = [os.path.join(ROOT, "qoaudio_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "qoaudio_amd", "csrc"))
             if f.endswith((".hip", ".cpp", ".h", ".inc"))] + [os.path.join(ROOT, "include", "qoaudio_amd.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-j4", "-C", os.path.join(ROOT, "qoaudio_amd", "csrc")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-j8", "-C", os.path.join(ROOT, "qoaudio_amd", "csrc")], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
