@@ -59,6 +59,34 @@ def test_two_rank_control_flow_on_one_gpu(gpu, oracle):
     assert line["decode"]["header_mismatches"] == 0
 
 
+def test_the_drivers_command_line_for_n_gpus(gpu, oracle):
+    """The command the driver runs for N > 1, verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with N = 2 on this one-GPU box (both
+    ranks on device 0, gather over gloo): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher's environment, rank 0
+    alone prints, and its LAST line is the contract's record with the preflight in it."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QOA_BENCH_SHARE_GPU="1", QOA_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--clips", "64", "--frames", "8"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 2, out.stdout[-2000:]     # rank 0's two lines, nothing from rank 1
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["bit_exact_vs_oracle"] is True and line["gathered_shards_bit_exact_vs_oracle"] is True
+    assert line["gathered_bytes"] == 2 * 64 * gpu.encoded_size(2, 8 * 5120)
+    assert line["preflight"]["gather_1mb_ok"] is True and "error" not in line["preflight"]
+    assert "cpu_baseline" not in line and "e2e" not in line   # (N = 1 only)
+
+
 def test_two_rank_control_flow_at_config4_per_rank_shape(gpu, oracle):
     """The same two-rank run at config 4's REAL per-rank shape -- 1024 stereo clips x 256 frames per rank: 5.37 GB of PCM,
     1.08 GB encoded shards, two output buffers per rank and two 2.17 GB gather destinations on rank 0, rotated by the
