@@ -55,6 +55,8 @@ def baseline_block(d, src):
         row = (f"**{f(dec['kernel_ms_avg'], 3)} ms** median over {len(dec['kernel_ms_per_placement'])} "
                f"buffer placements ({', '.join(f(v, 3) for v in dec['kernel_ms_per_placement'])}) = {f(dec['value'] / 1e12, 2)} T samples/s = "
                f"**{f(rr['frac'], 3)} of the HBM peak** (best placement {f(rr['frac_best_placement'], 3)}, worst {f(rr['frac_worst_placement'], 3)})")
+        if rr.get("traffic"):
+            row += (f"; PMC traffic {rr['traffic'] / 1e9:.3f} GB = {rr['traffic'] / rr['algorithmic_bytes_per_launch']:.3f} x the algorithmic bytes")
         if "decode_value" in cpu:
             row += (f".  CPU (oracle decode_all, the same streams, 1 thread): {f(cpu['decode_value'] / 1e6, 0)} M samples/s -> "
                     f"{f(dec['value'] / cpu['decode_value'], 0)}x; PCM equal: {cpu.get('gpu_pcm_equals_cpu_pcm')}")
