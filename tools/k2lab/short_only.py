@@ -33,5 +33,4 @@ for name, pad in (("packed (40 bytes further off the grid per clip)", 0), ("16-b
         e0.record(); plan.run(enc, out); e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
-    ok = all(torch.equal(out[k * stride:k * stride + samples * ch].view(samples, ch), pcm_ref) for k, pcm_ref in ((0, None),) if pcm_ref is not None)
     print(f"{name:50s} {min(ms):.3f} ms (mean {sum(ms) / len(ms):.3f})", flush=True)
