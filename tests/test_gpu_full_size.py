@@ -107,3 +107,52 @@ def test_full_chip_decode_of_channel_counts_that_do_not_divide_a_wavefront(gpu, 
     for i in np.linspace(0, n_clips - 1, 24).astype(int):
         _, _, want = oracle.decode_all(host_enc[i].tobytes())
         assert np.array_equal(host[i], want), (channels, int(i))
+
+
+@pytest.mark.parametrize("channels,frames,tail", [(2, 16, 3082), (4, 8, 1217), (8, 4, 777)])
+def test_full_chip_decode_of_packed_clips_with_a_short_last_frame(gpu, oracle, channels, frames, tail):
+    """The reference fixture's shape (full frames + one short frame, src/lib.rs:1001-1031) packed back to back, a full chip of
+    it: clip i's PCM starts `i * tail * channels * 2 mod 128` bytes past a 128-byte line, so the batch runs through every offset
+    the channel count allows (stereo: all 16 multiples of 8), and ONE plan run takes K2u's absolute-line launch (off-grid full
+    frames + the on-grid ones that do not fill the chip alone), the general kernel K2 on the side stream (the short last
+    frames) and their shared cache lines (a clip's last line is its neighbour's first).  Every clip against the general
+    kernel alone (the same plan into a PCM base 2 bytes off the dword grid), the pattern around the batch untouched, 24 clips
+    spread over the batch against the oracle (src/lib.rs:291-330), every frame header verified."""
+    from qoaudio_amd import batch, synth
+    fpw = 64 // channels
+    n_clips = (2048 + 64) * fpw // frames                       # > 2048 wavefronts of full frames
+    samples = frames * 5120 + tail
+    step = (samples * channels * 2) % 128
+    assert step % 8 == 0 and step != 0
+    distinct = 32
+    base = synth.make_clips(distinct, samples, channels, 44100, device="cuda", first_index=4242)
+    pcm = base.repeat(((n_clips + distinct - 1) // distinct, 1, 1))[:n_clips].contiguous()
+    desc = gpu.QoaDesc(channels, 44100, samples)
+    clips, per_pcm, per_enc = batch.uniform_clips(n_clips, desc)
+    assert per_pcm == samples * channels
+    enc = torch.empty((n_clips, per_enc), dtype=torch.uint8, device="cuda")
+    batch.EncodePlan(clips).run(pcm, enc)
+    del pcm
+    dplan = batch.DecodePlan.from_clips(clips)
+    pad = 64
+    buf = torch.full((pad + n_clips * per_pcm + pad,), -4321, dtype=torch.int16, device="cuda")
+    assert buf.data_ptr() % 128 == 0
+    fast = buf[pad:pad + n_clips * per_pcm]                    # 128-byte aligned base: the absolute-line launch
+    dplan.run(enc, fast)
+    assert dplan.mismatches() == 0
+    assert bool((buf[:pad] == -4321).all()) and bool((buf[pad + n_clips * per_pcm:] == -4321).all())
+    fast = fast.clone()
+    buf.fill_(-4321)
+    slow = buf[pad + 1:pad + 1 + n_clips * per_pcm]            # 2 bytes off the dword grid: the general kernel
+    dplan.run(enc, slow)
+    assert dplan.mismatches() == 0
+    assert torch.equal(fast, slow)
+    host = fast.view(n_clips, per_pcm).cpu().numpy()
+    host_enc = enc.cpu().numpy()
+    seen = set()
+    for i in np.linspace(0, n_clips - 1, 24).astype(int):
+        seen.add((int(i) * step) % 128)
+        _, _, want = oracle.decode_all(host_enc[i].tobytes())
+        assert np.array_equal(host[i], want), (channels, int(i))
+    assert len(seen) >= 128 // np.gcd(step, 128) // 2          # the sampled clips sit at many different offsets
+    assert host_enc[0].tobytes() == oracle.encode_all(base[0].cpu().numpy().reshape(-1), channels, 44100, samples)
