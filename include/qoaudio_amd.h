@@ -63,7 +63,9 @@ enum {
 /* Display strings of the two error enums, src/lib.rs:877-906 ("IO error: " + detail for IoError). */
 const char *qoa_encode_strerror(int code);
 const char *qoa_decode_strerror(int code);
-/* Detail of the last IoError raised on this thread by this library (HIP error text, "buffer too small"...). */
+/* Detail of the last IoError raised on this thread by this library (HIP error text, "buffer too small"...).
+ * The library never aborts and no C++ exception leaves it: host memory exhaustion inside an entry point comes back as the
+ * family's IoError with the detail "out of host memory" (qoa_decoder_next: as a QOA_ITEM_ERROR item). */
 const char *qoa_last_error_detail(void);
 /* "qoaudio_amd <version> gfx950" */
 const char *qoa_version(void);

@@ -40,6 +40,21 @@ static int fail_msg(const char *msg, int code) {
     return code;
 }
 
+// No C++ exception may cross the C ABI ("never abort"): the host side keeps its tables in std::vector / std::string,
+// whose allocations throw.  Every `int` entry point below is a function-try-block that ends here: the caller gets the family's
+// IoError code and the reason in qoa_last_error_detail().  (What a half-built object held is released by its owner's
+// destructor where one exists; under memory exhaustion a leaked host table is the lesser evil.)
+static int on_exception(int io_code) noexcept {
+    try {
+        try { throw; }
+        catch (const std::bad_alloc &) { g_detail = "out of host memory"; }
+        catch (const std::exception &e) { g_detail = std::string("host exception: ") + e.what(); }
+        catch (...) { g_detail = "host exception"; }
+    } catch (...) { // (even the message could not be stored)
+    }
+    return io_code;
+}
+
 #define HIP_TRY(expr, code)                                          \
     do {                                                             \
         hipError_t _e = (expr);                                      \
@@ -175,7 +190,7 @@ static void make_chains(const qoa_clip &c, bool file_header, uint32_t samples_no
     }
 }
 
-extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uint32_t flags, qoa_encode_plan **out) {
+extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uint32_t flags, qoa_encode_plan **out) try {
     if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
     *out = nullptr;
     std::vector<EncChain> per_nch[kMaxChannels + 1];
@@ -197,8 +212,9 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
     std::stable_sort(order.begin(), order.end(),
                      [&](size_t a, size_t b) { return clips[a].desc.samples > clips[b].desc.samples; });
     for (size_t i : order) make_chains(clips[i], true, clips[i].desc.samples, per_nch[clips[i].desc.channels]);
-    auto *plan = new (std::nothrow) qoa_encode_plan();
+    std::unique_ptr<qoa_encode_plan> plan(new (std::nothrow) qoa_encode_plan()); // (released on every way out, a throw included)
     if (!plan) return fail_msg("out of memory", QOA_ENCODE_IO_ERROR);
+    plan->groups.reserve(kMaxChannels);
     plan->pcm_bytes = pcm_bytes;
     plan->out_bytes = out_bytes;
     plan->samples = samples;
@@ -206,23 +222,18 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
     {
         hipError_t e = plan->stats.reserve(kCounters * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMemset(plan->stats.p, 0, kCounters * sizeof(uint64_t));
-        if (e != hipSuccess) {
-            delete plan;
-            return fail_hip(e, "encode plan counters", QOA_ENCODE_IO_ERROR);
-        }
+        if (e != hipSuccess) return fail_hip(e, "encode plan counters", QOA_ENCODE_IO_ERROR);
     }
     for (int nch = 1; nch <= kMaxChannels; nch++) {
         auto &v = per_nch[nch];
         if (v.empty()) continue;
         auto *g = new EncGroup();
-        plan->groups.push_back(g);
+        plan->groups.push_back(g); // (capacity reserved above: cannot throw between the two lines)
         g->nch = nch;
         g->n = (unsigned)v.size();
         g->cpw = pick_cpw(v.size(), flags);
-        if ((flags & QOA_PLAN_WAVE_STATS) && g->cpw != 4) {
-            delete plan;
+        if ((flags & QOA_PLAN_WAVE_STATS) && g->cpw != 4)
             return fail_msg("QOA_PLAN_WAVE_STATS needs the default packing (no QOA_PLAN_CPW_1 / _2)", QOA_ENCODE_IO_ERROR);
-        }
         hipError_t e = g->chains.reserve(v.size() * sizeof(EncChain));
         if (e == hipSuccess) e = g->lms.reserve(v.size() * 8 * sizeof(int32_t));
         if (e == hipSuccess && (flags & QOA_PLAN_WAVE_STATS)) {
@@ -231,25 +242,22 @@ extern "C" int qoa_encode_plan_create(const qoa_clip *clips, size_t n_clips, uin
             if (e == hipSuccess) e = hipMemset(g->wave_rec.p, 0, rec_bytes); // (a plan that never ran reports no wavefronts)
         }
         if (e == hipSuccess) e = hipMemcpy(g->chains.p, v.data(), v.size() * sizeof(EncChain), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            delete plan;
-            return fail_hip(e, "encode plan upload", QOA_ENCODE_IO_ERROR);
-        }
+        if (e != hipSuccess) return fail_hip(e, "encode plan upload", QOA_ENCODE_IO_ERROR);
     }
-    *out = plan;
+    *out = plan.release();
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" void qoa_encode_plan_free(qoa_encode_plan *plan) { delete plan; }
 
 extern "C" int qoa_encode_plan_bytes(const qoa_encode_plan *plan, uint64_t *pcm_bytes, uint64_t *out_bytes,
-                                     uint64_t *samples_i16) {
+                                     uint64_t *samples_i16) try {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     if (pcm_bytes) *pcm_bytes = plan->pcm_bytes;
     if (out_bytes) *out_bytes = plan->out_bytes;
     if (samples_i16) *samples_i16 = plan->samples;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // The LDS-table step form spends fewer issue slots per slice than the cheap-quotient register form but has one LDS round trip
 // per step on its serial chain: it only pays once a launch gives every SIMD about 8 wavefronts to cover that latency
@@ -268,7 +276,7 @@ static unsigned plan_kernel_flags(uint32_t pf) {
            ((pf & QOA_PLAN_NO_WIDE_FORM) ? 1024u : 0u);
 }
 
-extern "C" int qoa_encode_plan_launch_shape(const qoa_encode_plan *plan, qoa_launch_shape *shape) {
+extern "C" int qoa_encode_plan_launch_shape(const qoa_encode_plan *plan, qoa_launch_shape *shape) try {
     if (!plan || !shape) return fail_msg("null plan / shape", QOA_ENCODE_IO_ERROR);
     if (shape->struct_bytes < sizeof(qoa_launch_shape)) return fail_msg("qoa_launch_shape.struct_bytes too small", QOA_ENCODE_IO_ERROR);
     uint32_t waves = 0, cpw = 0, lds = 0, helper = 0, biggest = 0, launches = 0;
@@ -287,12 +295,12 @@ extern "C" int qoa_encode_plan_launch_shape(const qoa_encode_plan *plan, qoa_lau
     shape->helper_wavefronts = helper;
     shape->launches = launches;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // (the four-pointer form of rounds 1-3; round 4 had added a fifth out-parameter in place -- an ABI break for C callers,
 // advisor round 4 -- which now lives in qoa_launch_shape)
 extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t *wavefronts, uint32_t *chains_per_wavefront,
-                                           uint32_t *lds_table_form) {
+                                           uint32_t *lds_table_form) try {
     qoa_launch_shape sh;
     sh.struct_bytes = sizeof sh;
     int rc = qoa_encode_plan_launch_shape(plan, &sh);
@@ -301,13 +309,13 @@ extern "C" int qoa_encode_plan_launch_info(const qoa_encode_plan *plan, uint32_t
     if (chains_per_wavefront) *chains_per_wavefront = sh.chains_per_wavefront;
     if (lds_table_form) *lds_table_form = sh.lds_table_form;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // kernel flags: bit0 rolled tail path for every slice, bit1 fresh LMS state (QoaEncoder::new's, src/lib.rs:346-352),
 // bit2 no i16-packed fast path, bit3 no speculative (penalty-free) steps, bit4 speculative steps on the LDS quantiser table,
 // bit5 no cheap-quotient speculative steps, bit6 no penalty form, bit7 no 32-bit block statement,
 // bit8 no helper wavefronts, bit9 helper wavefronts whatever the launch size, bit10 no wide form
-extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) {
+extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, uint8_t *d_out, void *stream) try {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     const unsigned kflags = 2u | plan_kernel_flags(plan->flags);
     for (auto *g : plan->groups) {
@@ -321,10 +329,10 @@ extern "C" int qoa_encode_plan_run(qoa_encode_plan *plan, const int16_t *d_pcm, 
                 QOA_ENCODE_IO_ERROR);
     }
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_slices, uint64_t *unpacked_slices,
-                                     uint64_t *speculation_misses) {
+                                     uint64_t *speculation_misses) try {
     if (!plan) return fail_msg("null plan", QOA_ENCODE_IO_ERROR);
     if (!(plan->flags & QOA_PLAN_COUNTERS)) return fail_msg("plan was created without QOA_PLAN_COUNTERS", QOA_ENCODE_IO_ERROR);
     uint64_t h[3] = {0, 0, 0};
@@ -334,9 +342,9 @@ extern "C" int qoa_encode_plan_stats(qoa_encode_plan *plan, uint64_t *declined_s
     if (unpacked_slices) *unpacked_slices = h[1];
     if (speculation_misses) *speculation_misses = h[2];
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
-extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n) {
+extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, size_t n) try {
     if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
     if (!(plan->flags & QOA_PLAN_COUNTERS)) return fail_msg("plan was created without QOA_PLAN_COUNTERS", QOA_ENCODE_IO_ERROR);
     std::vector<uint64_t> h(kCounters);
@@ -344,7 +352,7 @@ extern "C" int qoa_encode_plan_counters(qoa_encode_plan *plan, uint64_t *out, si
     HIP_TRY(hipMemcpy(h.data(), plan->stats.p, kCounters * sizeof(uint64_t), hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
     for (size_t i = 0; i < n; i++) out[i] = i < kCounters ? h[i] : 0;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // Issue slots per slice of each step form's block loop as tools/gen_slice_asm.py generates it (the cheap-quotient
 // loop 519, exact-quotient speculative 598 (the LDS-table form 477 + 26 LDS reads is reported in the same column), penalty 586,
@@ -358,7 +366,7 @@ static const double kCyclesPerIssue = 4.06;
 // winner's LDS round trip: measured 5 % (32-bit statement) to 10 % (cheap-quotient form) of a slice (profiles/r05_k1_slack.md)
 static const double kLoopOverhead = 1.10;
 
-extern "C" int qoa_encode_plan_wave_stats(qoa_encode_plan *plan, qoa_wave_stats *out) {
+extern "C" int qoa_encode_plan_wave_stats(qoa_encode_plan *plan, qoa_wave_stats *out) try {
     if (!plan || !out) return fail_msg("null plan / out", QOA_ENCODE_IO_ERROR);
     if (!(plan->flags & QOA_PLAN_WAVE_STATS)) return fail_msg("plan was created without QOA_PLAN_WAVE_STATS", QOA_ENCODE_IO_ERROR);
     if (out->struct_bytes < sizeof(qoa_wave_stats)) return fail_msg("qoa_wave_stats.struct_bytes too small", QOA_ENCODE_IO_ERROR);
@@ -406,7 +414,7 @@ extern "C" int qoa_encode_plan_wave_stats(qoa_encode_plan *plan, qoa_wave_stats 
         out->cycles_per_slice_min = cps.front();
     }
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // Host-memory batch encode: time-sliced pipeline
@@ -674,7 +682,7 @@ static int host_pipe_encode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
     return QOA_OK;
 }
 
-extern "C" int qoa_host_pipeline_create(qoa_host_pipeline **out) {
+extern "C" int qoa_host_pipeline_create(qoa_host_pipeline **out) try {
     if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
     *out = nullptr;
     auto *p = new (std::nothrow) qoa_host_pipeline();
@@ -683,22 +691,22 @@ extern "C" int qoa_host_pipeline_create(qoa_host_pipeline **out) {
     if (e != hipSuccess) { delete p; return fail_hip(e, "qoa_host_pipeline_create", QOA_ENCODE_IO_ERROR); }
     *out = p;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" void qoa_host_pipeline_free(qoa_host_pipeline *p) { delete p; }
 
 extern "C" int qoa_host_pipeline_encode(qoa_host_pipeline *p, const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm,
-                                        uint8_t *h_out, uint32_t chunk_frames) {
+                                        uint8_t *h_out, uint32_t chunk_frames) try {
     if (!p) return fail_msg("null pipeline", QOA_ENCODE_IO_ERROR);
     return host_pipe_encode(*p, clips, n_clips, h_pcm, h_out, chunk_frames);
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // one-shot form: a pipeline that lives for one call (streams, events and staging buffers are set up and torn down)
 extern "C" int qoa_encode_batch_host(const qoa_clip *clips, size_t n_clips, const int16_t *h_pcm, uint8_t *h_out,
-                                     uint32_t chunk_frames) {
+                                     uint32_t chunk_frames) try {
     qoa_host_pipeline P;
     return host_pipe_encode(P, clips, n_clips, h_pcm, h_out, chunk_frames);
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // QoaEncoder handle
@@ -711,7 +719,7 @@ struct qoa_encoder {
     ~qoa_encoder() { if (stream) (void)hipStreamDestroy(stream); }
 };
 
-extern "C" int qoa_encoder_new(const qoa_desc *desc, qoa_encoder **out) {
+extern "C" int qoa_encoder_new(const qoa_desc *desc, qoa_encoder **out) try {
     if (!out || !desc) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
     *out = nullptr;
     int rc = validate_desc(desc);
@@ -736,17 +744,17 @@ extern "C" int qoa_encoder_new(const qoa_desc *desc, qoa_encoder **out) {
     }
     *out = e;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" void qoa_encoder_free(qoa_encoder *enc) { delete enc; }
 
-extern "C" int qoa_encoder_write_header(const qoa_encoder *enc, uint8_t out[8]) { // src/lib.rs:404-408
+extern "C" int qoa_encoder_write_header(const qoa_encoder *enc, uint8_t out[8]) try { // src/lib.rs:404-408
     if (!enc || !out) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
     out[0] = 'q'; out[1] = 'o'; out[2] = 'a'; out[3] = 'f';
     uint32_t s = enc->desc.samples;
     out[4] = (uint8_t)(s >> 24); out[5] = (uint8_t)(s >> 16); out[6] = (uint8_t)(s >> 8); out[7] = (uint8_t)s;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // Shared by encode() and encode_frame(): encode `frame_len_total` sample-times of the handle's stream
 // starting from the carried LMS state, with or without the 8-byte file header.
@@ -774,7 +782,7 @@ static int encoder_run(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint3
 }
 
 extern "C" int qoa_encoder_encode(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint8_t *out, size_t cap,
-                                  size_t *written) { // src/lib.rs:367-398
+                                  size_t *written) try { // src/lib.rs:367-398
     if (!enc) return fail_msg("null encoder", QOA_ENCODE_IO_ERROR);
     size_t channels = enc->desc.channels, total = enc->desc.samples;
     if (n_i16 != total * channels) return QOA_ENCODE_INVALID_SAMPLES; // :368-370
@@ -785,10 +793,10 @@ extern "C" int qoa_encoder_encode(qoa_encoder *enc, const int16_t *pcm, size_t n
     if (rc) return rc;
     if (written) *written = need;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" int qoa_encoder_encode_frame(qoa_encoder *enc, const int16_t *pcm, size_t n_i16, uint8_t *out, size_t cap,
-                                        size_t *written, size_t *frame_len_out) { // src/lib.rs:418-439
+                                        size_t *written, size_t *frame_len_out) try { // src/lib.rs:418-439
     if (!enc) return fail_msg("null encoder", QOA_ENCODE_IO_ERROR);
     size_t channels = enc->desc.channels;
     if (n_i16 == 0 || n_i16 % channels != 0) return QOA_ENCODE_INVALID_SAMPLES; // :424-426
@@ -803,33 +811,33 @@ extern "C" int qoa_encoder_encode_frame(qoa_encoder *enc, const int16_t *pcm, si
     if (written) *written = frame_size;
     if (frame_len_out) *frame_len_out = frame_len;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
-extern "C" int qoa_encoder_get_lms(qoa_encoder *enc, int32_t *state) {
+extern "C" int qoa_encoder_get_lms(qoa_encoder *enc, int32_t *state) try {
     if (!enc || !state) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpy(state, enc->lms.p, enc->desc.channels * 8 * sizeof(int32_t), hipMemcpyDeviceToHost),
             QOA_ENCODE_IO_ERROR);
     return QOA_OK;
-}
-extern "C" int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state) {
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
+extern "C" int qoa_encoder_set_lms(qoa_encoder *enc, const int32_t *state) try {
     if (!enc || !state) return fail_msg("null pointer", QOA_ENCODE_IO_ERROR);
     HIP_TRY(hipMemcpy(enc->lms.p, state, enc->desc.channels * 8 * sizeof(int32_t), hipMemcpyHostToDevice),
             QOA_ENCODE_IO_ERROR);
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // Test hook: the handle's launches take the step-form switches of a plan (QOA_PLAN_* debug flags; QOA_PLAN_COUNTERS is
 // ignored) -- the fuzz tests drive every form from hostile LMS states through set_lms + encode_frame.
-extern "C" int qoa_debug_encoder_set_plan_flags(qoa_encoder *enc, uint32_t flags) {
+extern "C" int qoa_debug_encoder_set_plan_flags(qoa_encoder *enc, uint32_t flags) try {
     if (!enc) return fail_msg("null encoder", QOA_ENCODE_IO_ERROR);
     enc->debug_plan_flags = flags & ~(uint32_t)QOA_PLAN_COUNTERS;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // Test hook: the 16 candidates of ONE slice through the device functions of the encode kernel.
 extern "C" int qoa_debug_encode_slice(const int32_t *state, const int16_t *samples, int len, int generic,
                                       uint64_t *total_rank, uint64_t *first_rank, uint64_t *slices,
-                                      int32_t *end_states) {
+                                      int32_t *end_states) try {
     if (!state || !samples || len < 1 || len > 20) return fail_msg("bad argument", QOA_ENCODE_IO_ERROR);
     int32_t smp[20] = {0};
     for (int i = 0; i < len; i++) smp[i] = samples[i];
@@ -849,17 +857,17 @@ extern "C" int qoa_debug_encode_slice(const int32_t *state, const int16_t *sampl
     if (slices) HIP_TRY(hipMemcpy(slices, b + o_slice, 128, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
     if (end_states) HIP_TRY(hipMemcpy(end_states, b + o_end, 512, hipMemcpyDeviceToHost), QOA_ENCODE_IO_ERROR);
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" int qoa_encode_all(const int16_t *pcm, size_t n_i16, const qoa_desc *desc, uint8_t *out, size_t cap,
-                              size_t *written) { // src/lib.rs:760-763
+                              size_t *written) try { // src/lib.rs:760-763
     qoa_encoder *e = nullptr;
     int rc = qoa_encoder_new(desc, &e);
     if (rc) return rc;
     rc = qoa_encoder_encode(e, pcm, n_i16, out, cap, written);
     qoa_encoder_free(e);
     return rc;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // stream walking (host bytes only)
@@ -1160,7 +1168,7 @@ static void frames_to_records(const std::vector<FrameRec> &frames, size_t first_
     if (samples_total) *samples_total = out - out_base;
 }
 
-extern "C" int qoa_stream_scan(const uint8_t *bytes, size_t len, qoa_stream_info *info) {
+extern "C" int qoa_stream_scan(const uint8_t *bytes, size_t len, qoa_stream_info *info) try {
     if (!info) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
     memset(info, 0, sizeof *info);
     info->in_new = 1;
@@ -1187,7 +1195,7 @@ extern "C" int qoa_stream_scan(const uint8_t *bytes, size_t len, qoa_stream_info
     info->n_frames = frames.size();
     for (auto &f : frames) info->n_samples += (uint64_t)f.n_out * f.channels;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // batch decode plan
@@ -1204,7 +1212,7 @@ static int plan_upload(qoa_decode_plan *plan, const std::vector<DecChain> &recs)
 
 extern "C" int qoa_decode_plan_from_streams(const uint8_t *const *streams, const size_t *len, const uint64_t *in_offset,
                                             const uint64_t *out_offset, size_t n_streams, int *status,
-                                            uint64_t *samples_out, qoa_decode_plan **out) {
+                                            uint64_t *samples_out, qoa_decode_plan **out) try {
     if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
     *out = nullptr;
     std::vector<DecChain> chains;
@@ -1234,18 +1242,18 @@ extern "C" int qoa_decode_plan_from_streams(const uint8_t *const *streams, const
         in_bytes += n;
         samples += n_i16;
     }
-    auto *plan = new (std::nothrow) qoa_decode_plan();
+    std::unique_ptr<qoa_decode_plan> plan(new (std::nothrow) qoa_decode_plan()); // (released on every way out, a throw included)
     if (!plan) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
     plan->in_bytes = in_bytes;
     plan->samples = samples;
     plan->pcm_bytes = samples * 2;
-    int rc = plan_upload(plan, chains);
-    if (rc) { delete plan; return rc; }
-    *out = plan;
+    int rc = plan_upload(plan.get(), chains);
+    if (rc) return rc;
+    *out = plan.release();
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
-extern "C" int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips, qoa_decode_plan **out) {
+extern "C" int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips, qoa_decode_plan **out) try {
     if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
     *out = nullptr;
     std::vector<DecChain> chains;
@@ -1279,41 +1287,41 @@ extern "C" int qoa_decode_plan_from_clips(const qoa_clip *clips, size_t n_clips,
         in_bytes += qoa_encoded_size(d.channels, d.samples);
         samples += (uint64_t)d.samples * d.channels;
     }
-    auto *plan = new (std::nothrow) qoa_decode_plan();
+    std::unique_ptr<qoa_decode_plan> plan(new (std::nothrow) qoa_decode_plan()); // (released on every way out, a throw included)
     if (!plan) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
     plan->in_bytes = in_bytes;
     plan->samples = samples;
     plan->pcm_bytes = samples * 2;
-    int rc = plan_upload(plan, chains);
-    if (rc) { delete plan; return rc; }
-    *out = plan;
+    int rc = plan_upload(plan.get(), chains);
+    if (rc) return rc;
+    *out = plan.release();
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 extern "C" void qoa_decode_plan_free(qoa_decode_plan *plan) { delete plan; }
 
 extern "C" int qoa_decode_plan_bytes(const qoa_decode_plan *plan, uint64_t *in_bytes, uint64_t *pcm_bytes,
-                                     uint64_t *samples_i16) {
+                                     uint64_t *samples_i16) try {
     if (!plan) return fail_msg("null plan", QOA_DECODE_IO_ERROR);
     if (in_bytes) *in_bytes = plan->in_bytes;
     if (pcm_bytes) *pcm_bytes = plan->pcm_bytes;
     if (samples_i16) *samples_i16 = plan->samples;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
-extern "C" int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream) {
+extern "C" int qoa_decode_plan_run(qoa_decode_plan *plan, const uint8_t *d_in, int16_t *d_out, void *stream) try {
     if (!plan) return fail_msg("null plan", QOA_DECODE_IO_ERROR);
     HIP_TRY(plan->t.run(d_in, d_out, (hipStream_t)stream), QOA_DECODE_IO_ERROR);
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
-extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count) {
+extern "C" int qoa_decode_plan_mismatches(qoa_decode_plan *plan, uint32_t *count) try {
     if (!plan || !count) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
     // the runs may sit on non-blocking side streams, which the null stream's copy below does not wait for
     HIP_TRY(hipDeviceSynchronize(), QOA_DECODE_IO_ERROR);
     HIP_TRY(hipMemcpy(count, plan->t.counter_own, sizeof(uint32_t), hipMemcpyDeviceToHost), QOA_DECODE_IO_ERROR);
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // Host-memory batch decode: frame-sliced pipeline (the decode half)
@@ -1519,16 +1527,16 @@ static int host_pipe_decode(HostPipe &P, const qoa_clip *clips, size_t n_clips, 
 }
 
 extern "C" int qoa_host_pipeline_decode(qoa_host_pipeline *p, const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc,
-                                        int16_t *h_pcm, uint32_t chunk_frames) {
+                                        int16_t *h_pcm, uint32_t chunk_frames) try {
     if (!p) return fail_msg("null pipeline", QOA_DECODE_IO_ERROR);
     return host_pipe_decode(*p, clips, n_clips, h_enc, h_pcm, chunk_frames);
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 extern "C" int qoa_decode_batch_host(const qoa_clip *clips, size_t n_clips, const uint8_t *h_enc, int16_t *h_pcm,
-                                     uint32_t chunk_frames) {
+                                     uint32_t chunk_frames) try {
     qoa_host_pipeline P;
     return host_pipe_decode(P, clips, n_clips, h_enc, h_pcm, chunk_frames);
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // Multi-GPU batches behind the C ABI (BASELINE config 4): ONE process, one host thread + one time-sliced
@@ -1560,7 +1568,7 @@ struct qoa_multi {
     }
 };
 
-extern "C" int qoa_multi_create_flags(const int *devices, int n_devices, uint32_t flags, qoa_multi **out) {
+extern "C" int qoa_multi_create_flags(const int *devices, int n_devices, uint32_t flags, qoa_multi **out) try {
     if (!out) return fail_msg("null out pointer", QOA_ENCODE_IO_ERROR);
     *out = nullptr;
     if (!devices || n_devices < 1) return fail_msg("qoa_multi_create: empty device list", QOA_ENCODE_IO_ERROR);
@@ -1610,21 +1618,21 @@ extern "C" int qoa_multi_create_flags(const int *devices, int n_devices, uint32_
     if (rc != QOA_OK) { delete m; return rc; }
     *out = m;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
-extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out) {
+extern "C" int qoa_multi_create(const int *devices, int n_devices, qoa_multi **out) try {
     return qoa_multi_create_flags(devices, n_devices, 0u, out);
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" void qoa_multi_free(qoa_multi *m) { delete m; }
 
-extern "C" int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t *first, size_t *count) {
+extern "C" int qoa_multi_shard(size_t n_clips, int n_devices, int index, size_t *first, size_t *count) try {
     if (n_devices < 1 || index < 0 || index >= n_devices || !first || !count) return fail_msg("qoa_multi_shard: bad arguments", QOA_ENCODE_IO_ERROR);
     const size_t base = n_clips / (size_t)n_devices, extra = n_clips % (size_t)n_devices, i = (size_t)index;
     *first = i * base + std::min(i, extra);
     *count = base + (i < extra ? 1 : 0);
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 // runs fn(i) for every device that has work, each call bound to its device: on one host thread per device -- a single
 // working device runs on the caller's thread -- first failure wins.  Nothing may leave through the C ABI as an exception:
@@ -1687,7 +1695,7 @@ static int multi_run(qoa_multi *m, size_t n_clips, int io_error, Fn fn) {
 }
 
 extern "C" int qoa_multi_encode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const int16_t *const *pcm, uint8_t *out,
-                                uint32_t chunk_frames) {
+                                uint32_t chunk_frames) try {
     if (!m || !clips || !pcm || !out) return fail_msg("qoa_multi_encode: null pointer", QOA_ENCODE_IO_ERROR);
     for (size_t i = 0; i < n_clips; i++) { // the whole batch is validated before any device starts (src/lib.rs:336-344)
         const int rc = validate_desc(&clips[i].desc);
@@ -1697,20 +1705,20 @@ extern "C" int qoa_multi_encode(qoa_multi *m, const qoa_clip *clips, size_t n_cl
         if (!pcm[i]) return fail_msg("qoa_multi_encode: null PCM base of a shard", QOA_ENCODE_IO_ERROR);
         return host_pipe_encode(*m->pipes[(size_t)i], clips + first, count, pcm[i], out, chunk_frames);
     });
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" int qoa_multi_decode(qoa_multi *m, const qoa_clip *clips, size_t n_clips, const uint8_t *enc, int16_t *const *pcm,
-                                uint32_t chunk_frames) {
+                                uint32_t chunk_frames) try {
     if (!m || !clips || !pcm || !enc) return fail_msg("qoa_multi_decode: null pointer", QOA_DECODE_IO_ERROR);
     return multi_run(m, n_clips, QOA_DECODE_IO_ERROR, [&](int i, size_t first, size_t count) {
         if (!pcm[i]) return fail_msg("qoa_multi_decode: null PCM base of a shard", QOA_DECODE_IO_ERROR);
         return host_pipe_decode(*m->pipes[(size_t)i], clips + first, count, enc, pcm[i], chunk_frames);
     });
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 // one-shot forms: the handle lives for one call
 extern "C" int qoa_encode_batch_multi(const int *devices, int n_devices, const qoa_clip *clips, size_t n_clips,
-                                      const int16_t *const *pcm, uint8_t *out, uint32_t chunk_frames) {
+                                      const int16_t *const *pcm, uint8_t *out, uint32_t chunk_frames) try {
     qoa_multi *m = nullptr;
     int rc = qoa_multi_create(devices, n_devices, &m);
     if (rc != QOA_OK) return rc;
@@ -1719,10 +1727,10 @@ extern "C" int qoa_encode_batch_multi(const int *devices, int n_devices, const q
     qoa_multi_free(m);
     g_detail = keep;
     return rc;
-}
+} catch (...) { return on_exception(QOA_ENCODE_IO_ERROR); }
 
 extern "C" int qoa_decode_batch_multi(const int *devices, int n_devices, const qoa_clip *clips, size_t n_clips, const uint8_t *enc,
-                                      int16_t *const *pcm, uint32_t chunk_frames) {
+                                      int16_t *const *pcm, uint32_t chunk_frames) try {
     qoa_multi *m = nullptr;
     int rc = qoa_multi_create(devices, n_devices, &m);
     if (rc != QOA_OK) return rc == QOA_ENCODE_IO_ERROR ? QOA_DECODE_IO_ERROR : rc;
@@ -1731,7 +1739,7 @@ extern "C" int qoa_decode_batch_multi(const int *devices, int n_devices, const q
     qoa_multi_free(m);
     g_detail = keep;
     return rc;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 // ------------------------------------------------------------------------------------------------
 // QoaDecoder handle
@@ -1846,7 +1854,7 @@ static bool decoder_refill(qoa_decoder *dec, int *rc) {
     return true;
 }
 
-extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **out) { // src/lib.rs:127-169
+extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **out) try { // src/lib.rs:127-169
     if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
     *out = nullptr;
     if (len < 4) return fail_msg("failed to fill whole buffer", QOA_DECODE_IO_ERROR); // read_u32_be -> UnexpectedEof
@@ -1854,18 +1862,19 @@ extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **o
     if (len < 8) return fail_msg("failed to fill whole buffer", QOA_DECODE_IO_ERROR);
     auto *dec = new (std::nothrow) qoa_decoder();
     if (!dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+    std::unique_ptr<qoa_decoder> guard(dec); // (released on every way out, a throw included)
     dec->data.assign(bytes, bytes + len);
     dec->pos = 8;
     uint32_t samples = be32(bytes + 4);
     dec->w.mode = samples == 0 ? kStreaming : kFixed;
     dec->w.fixed_samples = samples;
     int rc = decoder_advance(dec);
-    if (rc) { delete dec; return rc; }
+    if (rc) { guard.reset(); return rc; }
     if (dec->w.mode == kFixed) {
         // the first frame header + LMS are parsed inside new(): its errors are new()'s errors (:161-166)
         if (dec->frames.empty()) {
             int t = dec->terminal;
-            delete dec;
+            guard.reset();
             if (t == kTermEnd) return QOA_DECODE_NO_SAMPLES;
             if (t == QOA_DECODE_IO_ERROR) g_detail = "failed to fill whole buffer";
             return t;
@@ -1874,22 +1883,23 @@ extern "C" int qoa_decoder_new(const uint8_t *bytes, size_t len, qoa_decoder **o
         dec->current.sample_rate = dec->frames[0].rate;
         dec->current.num_samples_per_channel = dec->frames[0].nspc;
     }
-    *out = dec;
+    *out = guard.release();
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 // QoaDecoder::new over a reader that is pulled lazily (src/lib.rs:127-169): the magic and the sample count now, the first
 // frame inside new() when the count is non-zero (the reference parses its header + LMS there, :161-166), every later frame
 // when Iterator::next runs out of samples.
-extern "C" int qoa_decoder_new_reader(qoa_read_fn read, void *ctx, qoa_decoder **out) {
+extern "C" int qoa_decoder_new_reader(qoa_read_fn read, void *ctx, qoa_decoder **out) try {
     if (!out) return fail_msg("null out pointer", QOA_DECODE_IO_ERROR);
     *out = nullptr;
     if (!read) return fail_msg("null reader callback", QOA_DECODE_IO_ERROR);
     auto *dec = new (std::nothrow) qoa_decoder();
     if (!dec) return fail_msg("out of memory", QOA_DECODE_IO_ERROR);
+    std::unique_ptr<qoa_decoder> guard(dec); // (released on every way out, a throw included)
     dec->read = read;
     dec->read_ctx = ctx;
-    auto fail = [&](int code, const char *msg) { if (msg) g_detail = msg; delete dec; return code; };
+    auto fail = [&](int code, const char *msg) { if (msg) g_detail = msg; guard.reset(); return code; };
     if (reader_pull(dec, 4) < 4) return fail(QOA_DECODE_IO_ERROR, dec->read_failed ? "reader callback failed" : "failed to fill whole buffer");
     if (be32(dec->data.data()) != kMagic) return fail(QOA_DECODE_NOT_QOA_FILE, nullptr);
     if (reader_pull(dec, 4) < 4) return fail(QOA_DECODE_IO_ERROR, dec->read_failed ? "reader callback failed" : "failed to fill whole buffer");
@@ -1910,31 +1920,31 @@ extern "C" int qoa_decoder_new_reader(qoa_read_fn read, void *ctx, qoa_decoder *
         dec->current.sample_rate = dec->frames[0].rate;
         dec->current.num_samples_per_channel = dec->frames[0].nspc;
     }
-    *out = dec;
+    *out = guard.release();
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
-extern "C" int qoa_decoder_new_streaming(qoa_decoder **out) { // src/lib.rs:632-638
+extern "C" int qoa_decoder_new_streaming(qoa_decoder **out) try { // src/lib.rs:632-638
     static const uint8_t hdr[8] = {'q', 'o', 'a', 'f', 0, 0, 0, 0};
     return qoa_decoder_new(hdr, 8, out);
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 extern "C" void qoa_decoder_free(qoa_decoder *dec) { delete dec; }
 
-extern "C" int qoa_decoder_mode(const qoa_decoder *dec, qoa_mode *mode) {
+extern "C" int qoa_decoder_mode(const qoa_decoder *dec, qoa_mode *mode) try {
     if (!dec || !mode) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
     mode->kind = dec->w.mode == kStreaming ? QOA_MODE_STREAMING : QOA_MODE_FIXED_SAMPLES;
     mode->channels = dec->w.fixed_channels;
     mode->sample_rate = dec->w.fixed_rate;
     mode->samples = dec->w.fixed_samples;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
-extern "C" int qoa_decoder_current_frame_header(const qoa_decoder *dec, qoa_frame_header *h) {
+extern "C" int qoa_decoder_current_frame_header(const qoa_decoder *dec, qoa_frame_header *h) try {
     if (!dec || !h) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
     *h = dec->current;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 extern "C" double qoa_decoder_total_duration(const qoa_decoder *dec) { // src/lib.rs:190-201
     if (!dec || dec->w.mode == kStreaming) return -1.0;
@@ -1942,7 +1952,7 @@ extern "C" double qoa_decoder_total_duration(const qoa_decoder *dec) { // src/li
 }
 
 // Iterator::next (src/lib.rs:668-692) replayed over the pre-decoded frames.
-extern "C" int qoa_decoder_next(qoa_decoder *dec, qoa_item *item) {
+extern "C" int qoa_decoder_next(qoa_decoder *dec, qoa_item *item) try {
     if (!dec || !item) return fail_msg("null pointer", QOA_DECODE_IO_ERROR);
     memset(item, 0, sizeof *item);
     if (dec->finished_err) { item->kind = QOA_ITEM_END; return QOA_OK; }
@@ -1995,6 +2005,11 @@ extern "C" int qoa_decoder_next(qoa_decoder *dec, qoa_item *item) {
         dec->finished_err = true;
         return QOA_OK;
     }
+} catch (...) { // (next() reports through the item: Some(Err(IoError)), after which the iterator is finished -- src/lib.rs:668-692)
+    const int rc = on_exception(QOA_DECODE_IO_ERROR);
+    if (item) { item->kind = QOA_ITEM_ERROR; item->error = rc; }
+    if (dec) dec->finished_err = true;
+    return QOA_OK;
 }
 
 extern "C" size_t qoa_decoder_read_samples(qoa_decoder *dec, int16_t *out, size_t cap) {
@@ -2009,7 +2024,7 @@ extern "C" size_t qoa_decoder_read_samples(qoa_decoder *dec, int16_t *out, size_
 }
 
 extern "C" int qoa_decoder_decode_frame(qoa_decoder *dec, const uint8_t *frame, size_t len, int16_t *out, size_t cap,
-                                        size_t *n_out) { // src/lib.rs:641-651
+                                        size_t *n_out) try { // src/lib.rs:641-651
     if (!dec) return fail_msg("null decoder", QOA_DECODE_IO_ERROR);
     if (dec->finished_err) { if (n_out) *n_out = 0; return QOA_OK; }
     if (len) {
@@ -2045,10 +2060,10 @@ extern "C" int qoa_decoder_decode_frame(qoa_decoder *dec, const uint8_t *frame, 
         }
     }
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }
 
 extern "C" int qoa_decode_all(const uint8_t *bytes, size_t len, uint8_t *channels, uint32_t *sample_rate, int16_t *out,
-                              size_t cap, size_t *n_out) { // src/lib.rs:713-747
+                              size_t cap, size_t *n_out) try { // src/lib.rs:713-747
     qoa_decoder *dec = nullptr;
     int rc = qoa_decoder_new(bytes, len, &dec);
     if (rc) return rc;
@@ -2082,4 +2097,4 @@ extern "C" int qoa_decode_all(const uint8_t *bytes, size_t len, uint8_t *channel
     if (sample_rate) *sample_rate = sr;
     if (n_out) *n_out = n;
     return QOA_OK;
-}
+} catch (...) { return on_exception(QOA_DECODE_IO_ERROR); }

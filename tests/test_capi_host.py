@@ -413,3 +413,55 @@ def test_multi_gpu_and_lazy_reader_fail_loudly_without_a_device():
         with pytest.raises(q.DecodeError) as e:
             q.QoaDecoder(io.BytesIO(data))
         assert e.value.kind == kind
+
+
+_OOM_CHILD = r"""
+import ctypes as C, resource, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from qoaudio_amd import _lib
+L = _lib.lib()
+n_frames = 3_000_000                                   # 1 channel, 1 slice of 20 samples per frame: 32 bytes each
+frame = np.zeros(32, np.uint8)
+frame[0] = 1; frame[1:4] = (0, 0xac, 0x44); frame[4:6] = (0, 20); frame[6:8] = (0, 32)
+buf = np.empty(8 + 32 * n_frames, np.uint8)
+buf[:4] = np.frombuffer(b"qoaf", np.uint8); buf[4:8] = np.frombuffer((20 * n_frames).to_bytes(4, "big"), np.uint8)
+buf[8:] = np.tile(frame, n_frames)
+info = _lib.StreamInfo()
+assert L.qoa_stream_scan(buf.ctypes.data_as(C.c_void_p), 8 + 32 * 1000, C.byref(info)) == 0   # (warm: everything loaded)
+vm = [int(l.split()[1]) * 1024 for l in open("/proc/self/status") if l.startswith("VmSize")][0]
+soft0, hard0 = resource.getrlimit(resource.RLIMIT_AS)
+resource.setrlimit(resource.RLIMIT_AS, (vm + (24 << 20), hard0))   # soft limit only; the frame table needs far more than 24 MB
+rc = L.qoa_stream_scan(buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(info))
+detail = L.qoa_last_error_detail().decode()
+resource.setrlimit(resource.RLIMIT_AS, (soft0, hard0))
+print("RC", rc, detail)
+rc2 = L.qoa_stream_scan(buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(info))       # and the library still works
+print("AGAIN", rc2, info.terminal)
+"""
+
+
+def test_no_exception_crosses_the_c_abi_when_host_memory_runs_out():
+    """SURVEY 8(b): "never abort".  The host side keeps its tables in std::vector; with the address space capped, the walk of a
+    stream of 3,000,000 frames cannot grow its frame table: the entry point must come back with the family's IoError and a
+    reason -- not std::terminate -- and work again once memory is there.  (Child process: the cap must not hit pytest.)"""
+    import sys
+    out = subprocess.run([sys.executable, "-c", _OOM_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    assert lines["RC"].split(" ", 1) == ["5", "out of host memory"], out.stdout       # QOA_DECODE_IO_ERROR
+    assert lines["AGAIN"].split()[0] == "0"
+
+
+def test_every_int_entry_point_is_a_function_try_block():
+    """... and that holds for every `int` entry point of the C ABI, mechanically: `extern "C" int qoa_x(...) try {{ ... }}
+    catch (...) {{ return on_exception(...); }}` (one-line bodies that cannot allocate are exempt)."""
+    src = open(os.path.join(ROOT, "qoaudio_amd", "csrc", "qoa_capi.cpp")).read()
+    heads = re.findall(r'^extern "C" int (qoa_\w+)\([^{;]*\)\s*(try\s*)?\{(.*)$', src, flags=re.M)
+    assert len(heads) >= 40
+    for name, is_try, rest in heads:
+        one_line = rest.rstrip().endswith("}")
+        assert is_try or one_line, f"{name} can throw across the C ABI"
+    # (qoa_decoder_next reports through its item, as Iterator::next does: its handler fills in Some(Err(IoError)))
+    assert src.count("} catch (...) { return on_exception(QOA_") + 1 == sum(1 for _, t, _ in heads if t)
+    assert "item->kind = QOA_ITEM_ERROR; item->error = rc;" in src
