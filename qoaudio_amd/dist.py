@@ -55,11 +55,13 @@ class _PaddedWork:
     received them into scratch blocks; wait() waits for the collective and then trims the blocks into `out` (on the
     current stream for device tensors: the work's wait() orders that stream behind the collective)."""
 
-    def __init__(self, work, parts, counts, out):
+    def __init__(self, work, parts, counts, out, send=None):
         self._work, self._parts, self._counts, self._out = work, parts, counts, out
+        self._send = send  # (the padded copy this rank sends must outlive the collective: held until wait())
 
     def wait(self):
         ok = self._work.wait()
+        self._send = None
         if self._parts is not None:
             for (a, b), p in zip(self._counts, self._parts):
                 self._out[a:b].copy_(p[: b - a])
@@ -89,11 +91,11 @@ def gather_encoded_async(local: torch.Tensor, n_total: int, dst: int = 0, group=
         if send.is_cuda and dist.get_backend(group) == "gloo":
             send = send.cpu()
         if rank != dst:
-            return _PaddedWork(dist.gather(send, gather_list=None, dst=dst, group=group, async_op=True), None, counts, None), None
+            return _PaddedWork(dist.gather(send, gather_list=None, dst=dst, group=group, async_op=True), None, counts, None, send), None
         if out is None:
             out = torch.empty((n_total, local.shape[1]), dtype=local.dtype, device=local.device)
         parts = [torch.empty((n_max, local.shape[1]), dtype=send.dtype, device=send.device) for _ in range(world)]
-        return _PaddedWork(dist.gather(send, gather_list=parts, dst=dst, group=group, async_op=True), parts, counts, out), out
+        return _PaddedWork(dist.gather(send, gather_list=parts, dst=dst, group=group, async_op=True), parts, counts, out, send), out
     if send.is_cuda and dist.get_backend(group) == "gloo":  # debug path only (see init_from_env): host-staged, synchronous
         host = send.cpu()
         parts = [torch.empty_like(host) for _ in counts] if rank == dst else None
