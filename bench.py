@@ -242,11 +242,14 @@ def decode_record(dplan, per_pair, kernel, traffic=None, traffic_note=None):
 
 def general_decode(q, batch, synth, dev, stream, rate):
     """The decode launches that are not whole wavefronts of full 1 / 2 / 4 / 8-channel frames: 6 and 3 channels (682 clips x 64
-    frames: channel counts that do not divide a wavefront), and a stereo batch whose clips end in a short frame like the
-    reference's fixture (63 full frames + 3,082 sample-times)."""
+    frames: channel counts that do not divide a wavefront; and the same at config 3's amount of work), and a stereo batch whose
+    clips end in a short frame like the reference's fixture (63 full frames + 3,082 sample-times)."""
     from oracle import oracle as O
     res = {}
     for name, n_clips, ch, samples, pad in (("6ch", 682, 6, 64 * 5120, 0), ("3ch", 682, 3, 64 * 5120, 0),
+                                            # the same kernels on config 3's amount of work (5.37 GB of PCM, ~8300 wavefronts: the 682-clip
+                                            # batches above are ONE generation of wavefronts, bound by a wavefront's lifetime)
+                                            ("3ch_full_chip", 2731, 3, 64 * 5120, 0), ("6ch_full_chip", 1366, 6, 64 * 5120, 0),
                                             ("stereo_short_last_frame", 1024, 2, 63 * 5120 + 3082, 2),
                                             ("stereo_short_last_frame_packed", 1024, 2, 63 * 5120 + 3082, 0),
                                             ("stereo_short_last_frame_line_aligned", 1024, 2, 63 * 5120 + 3082, 22)):
